@@ -1,0 +1,104 @@
+"""ctypes binding of ``libgendr_hip.so`` (C ABI in ``include/gendr_hip.h``).
+
+This is the only place the Python layer touches native code; it plays the role
+of the pybind11 module ``gendr.cuda.generalized_renderer`` of the reference
+(``gendr/cuda/generalized_renderer_cuda.cpp:230-237``).  There is no fallback:
+if the library is missing the import of any render entry point raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
+
+ABI_VERSION = 1
+
+
+class GendrParams(ctypes.Structure):
+    """``struct gendr_params`` of include/gendr_hip.h (field order is ABI)."""
+    _fields_ = [
+        ("image_size", ctypes.c_int),
+        ("dist_func", ctypes.c_int),
+        ("dist_scale", ctypes.c_float),
+        ("dist_squared", ctypes.c_int),
+        ("dist_shape", ctypes.c_float),
+        ("dist_shift", ctypes.c_float),
+        ("dist_eps", ctypes.c_float),
+        ("aggr_alpha_func", ctypes.c_int),
+        ("aggr_alpha_t_conorm_p", ctypes.c_float),
+        ("aggr_rgb_func", ctypes.c_int),
+        ("aggr_rgb_eps", ctypes.c_float),
+        ("aggr_rgb_gamma", ctypes.c_float),
+        ("near_", ctypes.c_float),
+        ("far_", ctypes.c_float),
+        ("double_side", ctypes.c_int),
+        ("texture_type", ctypes.c_int),
+        ("background", ctypes.c_float * 3),
+        ("background_from_buffer", ctypes.c_int),
+        ("texel_mode", ctypes.c_int),
+        ("cull", ctypes.c_int),
+    ]
+
+
+EXPORTS = (
+    "gendr_abi_version", "gendr_error_string", "gendr_face_record_floats", "gendr_validate",
+    "gendr_face_setup", "gendr_forward", "gendr_backward", "gendr_face_info",
+    "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
+    "gendr_cull_radius",
+)
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the library once.  Raises NativeLibraryError (never falls back) if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "gendr_amd: %s not found. Build it with `python -m gendr_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise NativeLibraryError("gendr_amd: %s does not export %s" % (LIB_PATH, name))
+    i, f, vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+    pp = ctypes.POINTER(GendrParams)
+    L.gendr_abi_version.restype = i
+    L.gendr_abi_version.argtypes = []
+    L.gendr_error_string.restype = ctypes.c_char_p
+    L.gendr_error_string.argtypes = [i]
+    L.gendr_face_record_floats.restype = i
+    L.gendr_face_record_floats.argtypes = [i, i]
+    L.gendr_validate.restype = i
+    L.gendr_validate.argtypes = [pp, i, i, i]
+    L.gendr_face_setup.restype = i
+    L.gendr_face_setup.argtypes = [vp, vp, vp, i, i, i, pp, vp]
+    L.gendr_forward.restype = i
+    L.gendr_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, pp, vp]
+    L.gendr_backward.restype = i
+    L.gendr_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, pp, vp]
+    L.gendr_face_info.restype = i
+    L.gendr_face_info.argtypes = [vp, vp, i, i, vp]
+    for name in ("gendr_sigmoid_forward", "gendr_sigmoid_backward"):
+        getattr(L, name).restype = f
+        getattr(L, name).argtypes = [i, f, f, f, f, f]
+    for name in ("gendr_t_conorm_forward", "gendr_t_conorm_backward"):
+        getattr(L, name).restype = f
+        getattr(L, name).argtypes = [i, f, f, i, f]
+    L.gendr_cull_radius.restype = f
+    L.gendr_cull_radius.argtypes = [pp]
+    if L.gendr_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("gendr_amd: ABI version mismatch (library %d, python %d); rebuild"
+                                 % (L.gendr_abi_version(), ABI_VERSION))
+    _lib = L
+    return _lib
+
+
+def error_string(code):
+    return lib().gendr_error_string(int(code)).decode()

@@ -1,0 +1,271 @@
+// gendr_capi.hip -- extern "C" entry points of libgendr_hip.so (declared in include/gendr_hip.h).
+//
+// Replaces the launchers forward_render_cuda / backward_render_cuda (kernel.cu:1071-1227) and the scalar
+// exports (kernel.cu:1230-1270) of the reference.  Differences by design: launches go to the caller's
+// stream (the reference uses the null stream, kernel.cu:1103,1118,1190), invalid options are rejected
+// with an error code instead of a device printf + NaN, nothing is allocated here.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "gendr_kernels.h"
+
+using namespace gendr;
+
+namespace {
+
+int texture_mode(const gendr_params* p, int T)
+{
+    if (p->texture_type == 1) return kTexVertex;
+    return T == 1 ? kTexSurface1 : kTexSurfaceN;
+}
+
+typedef void (*render_kernel_t)(const RenderArgs);
+
+// Specialised instantiations: the option sets of BASELINE.json's configs and of the reference's experiment
+// scripts get their own kernel (only their own CDF / t-conorm branch is compiled in); everything else runs
+// the runtime-dispatch kernel of its texture mode, which carries all 18 x 10 branches.
+struct KernelKey { int dist, alpha, rgb, sq, texm; };
+struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; };
+
+#define GENDR_SPECIALISE(D, A, RGB, SQ, TEXM) \
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM> }
+
+const KernelEntry kSpecialised[] = {
+    GENDR_SPECIALISE(kUniform,   kProbabilistic, 1, 0, kTexSurface1),   // C2 headline; library defaults
+    GENDR_SPECIALISE(kGaussian,  kEinstein,      1, 1, kTexSurface1),   // C3
+    GENDR_SPECIALISE(kLogistic,  kProbabilistic, 1, 0, kTexSurface1),   // C4
+    GENDR_SPECIALISE(kGamma,     kYager,         1, 0, kTexVertex),     // C5
+    GENDR_SPECIALISE(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // opt_shape / train_reconstruction soft renderer (hard RGB)
+    GENDR_SPECIALISE(kHeaviside, kAlphaHard,     0, 0, kTexSurface1),   // opt_shape hard renderer (opt_shape.py:148-159)
+};
+
+const KernelEntry kGeneric[3] = {
+    { {-1, -1, -1, -1, kTexSurface1}, render_forward_kernel<-1, -1, -1, -1, kTexSurface1>, render_backward_kernel<-1, -1, -1, -1, kTexSurface1> },
+    { {-1, -1, -1, -1, kTexVertex},   render_forward_kernel<-1, -1, -1, -1, kTexVertex>,   render_backward_kernel<-1, -1, -1, -1, kTexVertex> },
+    { {-1, -1, -1, -1, kTexSurfaceN}, render_forward_kernel<-1, -1, -1, -1, kTexSurfaceN>, render_backward_kernel<-1, -1, -1, -1, kTexSurfaceN> },
+};
+
+const KernelEntry& pick_kernel(const gendr_params* p, int texm)
+{
+    for (const KernelEntry& e : kSpecialised) {
+        if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == p->aggr_rgb_func &&
+            e.key.sq == (p->dist_squared ? 1 : 0) && e.key.texm == texm)
+            return e;
+    }
+    return kGeneric[texm];
+}
+
+int fill_args(RenderArgs& a, const float* face_records, const float* textures, int B, int nf, int T, const gendr_params* p)
+{
+    const int texm = texture_mode(p, T);
+    memset(&a, 0, sizeof(a));
+    a.boxes = face_records;
+    a.records = face_records + (size_t)B * nf * 4;
+    a.textures = textures;
+    a.B = B; a.nf = nf; a.T = T;
+    a.R = (int)sqrt((double)T);                                  // kernel.cu:1098
+    a.is = p->image_size;
+    a.tiles_x = (p->image_size + kTile - 1) / kTile;
+    a.tiles_per_image = a.tiles_x * a.tiles_x;
+    a.total_tiles = a.tiles_per_image * B;
+    a.p = *p;
+    a.thr = p->dist_eps * p->dist_scale;                         // float * float, kernel.cu:725
+    a.softmax_sum0 = expf(p->aggr_rgb_eps / p->aggr_rgb_gamma);  // kernel.cu:729
+    return texm;
+}
+
+int check_launch()
+{
+    return hipGetLastError() == hipSuccess ? GENDR_OK : GENDR_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gendr_abi_version(void) { return GENDR_ABI_VERSION; }
+
+const char* gendr_error_string(int code)
+{
+    switch (code) {
+    case GENDR_OK:              return "ok";
+    case GENDR_E_NULL:          return "a required pointer is NULL";
+    case GENDR_E_SHAPE:         return "B, nf, T or image_size out of range";
+    case GENDR_E_DIST_FUNC:     return "unknown dist_func id (valid: 0..17)";
+    case GENDR_E_ALPHA_FUNC:    return "unknown aggr_alpha_func id (valid: 0..9)";
+    case GENDR_E_RGB_FUNC:      return "aggr_rgb_func must be 0 (hard) or 1 (softmax)";
+    case GENDR_E_TEXTURE_TYPE:  return "texture_type must be 0 (surface) or 1 (vertex, T == 3)";
+    case GENDR_E_DIST_PARAM:    return "invalid distribution parameter (dist_scale < 0, dist_eps < 1, or gamma dist_shape < 0)";
+    case GENDR_E_TCONORM_PARAM: return "invalid t-conorm parameter p for the chosen aggr_alpha_func";
+    case GENDR_E_LAUNCH:        return "kernel launch failed";
+    case GENDR_E_WORKSPACE:     return "face_records workspace missing";
+    default:                    return "unknown error";
+    }
+}
+
+int gendr_face_record_floats(int texture_type, int T)
+{
+    const int texm = texture_type == 1 ? kTexVertex : (T == 1 ? kTexSurface1 : kTexSurfaceN);
+    return record_floats(texm) + 4;   // record + the compact cull box
+}
+
+int gendr_validate(const gendr_params* p, int B, int nf, int T)
+{
+    if (!p) return GENDR_E_NULL;
+    if (B < 0 || nf < 0 || T < 1 || p->image_size < 1 || p->image_size > 32768) return GENDR_E_SHAPE;
+    if ((long long)B * ((p->image_size + kTile - 1) / kTile) * ((p->image_size + kTile - 1) / kTile) > 0x7fffffffLL) return GENDR_E_SHAPE;
+    if (nf >= (1 << 24)) return GENDR_E_SHAPE;                   // face index is carried in a float (kernel.cu:853,998)
+    if (p->dist_func < 0 || p->dist_func >= kNumDist) return GENDR_E_DIST_FUNC;
+    if (p->aggr_alpha_func < 0 || p->aggr_alpha_func >= kNumAlpha) return GENDR_E_ALPHA_FUNC;
+    if (p->aggr_rgb_func != 0 && p->aggr_rgb_func != 1) return GENDR_E_RGB_FUNC;
+    if (p->texture_type != 0 && p->texture_type != 1) return GENDR_E_TEXTURE_TYPE;
+    if (p->texture_type == 1 && T != 3) return GENDR_E_TEXTURE_TYPE;
+    if (!(p->dist_scale >= 0.f) || !(p->dist_eps >= 1.f)) return GENDR_E_DIST_PARAM;   // functional/renderer.py:96,101
+    if ((p->dist_func == kGamma || p->dist_func == kGammaRev) && p->dist_shape < 0.f) return GENDR_E_DIST_PARAM;   // kernel.cu:296
+    const float tp = p->aggr_alpha_t_conorm_p;
+    switch (p->aggr_alpha_func) {
+    case kHamacher:       if (tp < 0.f) return GENDR_E_TCONORM_PARAM; break;                  // kernel.cu:491
+    case kFrank:          if (tp <= 0.f || tp == 1.f) return GENDR_E_TCONORM_PARAM; break;    // :501
+    case kYager: case kAczelAlsina: case kDombi:
+                          if (tp <= 0.f) return GENDR_E_TCONORM_PARAM; break;                 // :512,:522,:534
+    case kSchweizerSklar: if (tp >= 0.f) return GENDR_E_TCONORM_PARAM; break;                 // :552
+    default: break;
+    }
+    if (tp != tp) return GENDR_E_TCONORM_PARAM;
+    return GENDR_OK;
+}
+
+float gendr_sigmoid_forward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift)
+{
+    const DistParams d = {scale, dist_shape, dist_shift};
+    return cdf_rt(function_id, sign, x, d);
+}
+float gendr_sigmoid_backward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift)
+{
+    const DistParams d = {scale, dist_shape, dist_shift};
+    return pdf_rt(function_id, sign, x, d);
+}
+float gendr_t_conorm_forward(int t_conorm_id, float a_existing, float b_new, int face_id, float t_conorm_p)
+{
+    (void)face_id;
+    return tconorm_fold_rt(t_conorm_id, a_existing, b_new, t_conorm_p);
+}
+float gendr_t_conorm_backward(int t_conorm_id, float a_all, float b_current, int number_of_faces, float t_conorm_p)
+{
+    (void)number_of_faces;
+    return tconorm_grad_rt(t_conorm_id, a_all, b_current, t_conorm_p);
+}
+
+// Distance d (NDC) such that every outside pixel farther than d from the triangle is skipped by the
+// reference itself: either D(-x) <= 1e-6 (kernel.cu:784; searched against half that threshold so that the
+// few-ulp difference between host and device libm cannot matter) or d^2 >= dist_eps * tau (kernel.cu:769).
+float gendr_cull_radius(const gendr_params* p)
+{
+    if (!p || !p->cull) return INFINITY;
+    const float thr = p->dist_eps * p->dist_scale;
+    float r_eps = sqrtf(thr) * (1.f + 1e-6f) + 1e-30f;
+    if (!(r_eps == r_eps)) r_eps = INFINITY;
+    if (p->dist_func == kHeaviside) return 0.f;      // outside pixels: check_pixel_inside fails, fragment = 0 (kernel.cu:762-764)
+    const DistParams d = {p->dist_scale, p->dist_shape, p->dist_shift};
+    const double limit = 0.5 * kProbThreshold;
+    // x is the CDF argument: distance, or squared distance with dist_squared
+    const float x_hi = p->dist_squared ? 64.f : 8.f;
+    const float f_hi = cdf_rt(p->dist_func, -1.f, x_hi, d);
+    float r_cdf = INFINITY;
+    if (f_hi == f_hi && (double)f_hi <= limit) {
+        float lo = 0.f, hi = x_hi;                   // invariant: cdf(-hi) <= limit
+        const float f0 = cdf_rt(p->dist_func, -1.f, 0.f, d);
+        if (f0 == f0 && (double)f0 <= limit) hi = 0.f;
+        for (int it = 0; it < 64 && hi > lo; it++) {
+            const float mid = 0.5f * (lo + hi);
+            if (mid <= lo || mid >= hi) break;
+            const float fm = cdf_rt(p->dist_func, -1.f, mid, d);
+            if (fm == fm && (double)fm <= limit) hi = mid; else lo = mid;
+        }
+        r_cdf = p->dist_squared ? sqrtf(hi) : hi;
+        r_cdf = r_cdf * (1.f + 1e-6f);
+    }
+    return fminf(r_cdf, r_eps);
+}
+
+int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* stream)
+{
+    if (!faces || !faces_info) return GENDR_E_NULL;
+    const long total = (long)B * nf;
+    if (total == 0) return GENDR_OK;
+    const int blocks = (int)((total + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(face_info_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, faces, faces_info, total);
+    return check_launch();
+}
+
+int gendr_face_setup(const float* faces, const float* textures, float* face_records,
+                     int B, int nf, int T, const gendr_params* p, void* stream)
+{
+    const int v = gendr_validate(p, B, nf, T);
+    if (v != GENDR_OK) return v;
+    const long total = (long)B * nf;
+    if (total == 0) return GENDR_OK;
+    if (!faces || !textures) return GENDR_E_NULL;
+    if (!face_records) return GENDR_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int texm = texture_mode(p, T);
+    const int blocks = (int)((total + kThreads - 1) / kThreads);
+    const float sthr = sqrtf(p->dist_eps * p->dist_scale);       // sqrt(threshold), kernel.cu:725,747
+    const float cull_r = gendr_cull_radius(p);
+    float* boxes = face_records;
+    float* recs = face_records + (size_t)total * 4;
+    if (texm == kTexSurface1)
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
+    else if (texm == kTexVertex)
+        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
+    else
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
+    return check_launch();
+}
+
+int gendr_forward(const float* faces, const float* textures, float* rgba, float* aggrs_info,
+                  float* face_records, int B, int nf, int T, const gendr_params* p, void* stream)
+{
+    const int v = gendr_validate(p, B, nf, T);
+    if (v != GENDR_OK) return v;
+    if (!rgba || !aggrs_info) return GENDR_E_NULL;
+    if (B == 0) return GENDR_OK;
+    const int e = gendr_face_setup(faces, textures, face_records, B, nf, T, p, stream);
+    if (e != GENDR_OK) return e;
+
+    RenderArgs a;
+    const int texm = fill_args(a, face_records, textures, B, nf, T, p);
+    a.rgba = rgba;
+    a.aux = aggrs_info;
+    const KernelEntry& k = pick_kernel(p, texm);
+    hipLaunchKernelGGL(k.fwd, dim3(a.total_tiles), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+int gendr_backward(const float* faces, const float* textures, const float* rgba, const float* aggrs_info,
+                   const float* face_records, const float* grad_rgba,
+                   float* grad_faces, float* grad_textures,
+                   int B, int nf, int T, const gendr_params* p, void* stream)
+{
+    (void)faces;
+    const int v = gendr_validate(p, B, nf, T);
+    if (v != GENDR_OK) return v;
+    if (B == 0 || nf == 0) return GENDR_OK;
+    if (!textures || !rgba || !aggrs_info || !grad_rgba || !grad_faces || !grad_textures) return GENDR_E_NULL;
+    if (!face_records) return GENDR_E_WORKSPACE;
+
+    RenderArgs a;
+    const int texm = fill_args(a, face_records, textures, B, nf, T, p);
+    a.rgba = const_cast<float*>(rgba);
+    a.aux = const_cast<float*>(aggrs_info);
+    a.grad_rgba = grad_rgba;
+    a.grad_faces = grad_faces;
+    a.grad_textures = grad_textures;
+    a.p.background_from_buffer = 0;
+    const KernelEntry& k = pick_kernel(p, texm);
+    hipLaunchKernelGGL(k.bwd, dim3(a.total_tiles), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,399 @@
+// gendr_math.h -- scalar math of the generalized soft rasterizer (gfx950 device code and
+// the host scalar exports share it).
+//
+// What is computed: the 18 distribution CDFs D(s, x) and their x-derivatives, the 9
+// t-conorm fold steps T(a, b) and the closed-form d alpha_final / d D_f, as the reference
+// defines them in gendr/cuda/generalized_renderer_cuda_kernel.cu ("kernel.cu") :243-363,
+// :367-459, :474-563, :567-614.
+//
+// Parity policy: fp32 with the reference's double sub-expressions kept where
+// two or more double operations are chained before the value is rounded back to float
+// (a single double +,-,*,/ or sqrt on float operands rounds to the same float as the float
+// operation, so those are written in float).  Compiled with -ffp-contract=off: no FMA
+// contraction anywhere in this header.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define GENDR_HD __host__ __device__ __forceinline__
+
+namespace gendr {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kProbThreshold = 0.000001;   // kernel.cu:13
+constexpr int    kGammaSteps = 32;            // kernel.cu:16
+constexpr double kGammaCut = 15.;             // kernel.cu:17
+
+enum DistId : int {
+    kHeaviside = 0, kUniform = 1, kCubicHermite = 2, kWigner = 3, kGaussian = 4, kLaplace = 5,
+    kLogistic = 6, kGudermannian = 7, kCauchy = 8, kReciprocal = 9, kGumbelMax = 10, kGumbelMin = 11,
+    kExponential = 12, kExponentialRev = 13, kGamma = 14, kGammaRev = 15, kLevy = 16, kLevyRev = 17,
+    kNumDist = 18
+};
+enum AlphaId : int {
+    kAlphaHard = 0, kMax = 1, kProbabilistic = 2, kEinstein = 3, kHamacher = 4, kFrank = 5,
+    kYager = 6, kAczelAlsina = 7, kDombi = 8, kSchweizerSklar = 9, kNumAlpha = 10
+};
+
+struct DistParams {
+    float scale;   // tau
+    float shape;   // p of gamma
+    float shift;   // shift (in units of tau) of the one-sided families
+};
+
+GENDR_HD float quiet_nan() { return __builtin_nanf(""); }
+
+// normal CDF of a float argument (kernel.cu:293 calls CUDA's normcdf(float)).
+GENDR_HD float norm_cdf(float u) { return 0.5f * erfcf(-u * 0.70710678118654752440f); }
+
+// shifted abscissa of the one-sided families; `rev` mirrors it (kernel.cu:301-308, :339-345, :351-357)
+template <bool REV>
+GENDR_HD float shifted(float sign, float x, const DistParams& d)
+{
+    return REV ? -(sign * x - d.shift * d.scale) : (sign * x + d.shift * d.scale);
+}
+
+// ------------------------------------------------------------------------------------------
+// CDF.  One specialisation per distribution id so a kernel templated on the id carries only
+// its own branch; cdf_rt() below is the runtime-id dispatcher used by the generic kernels.
+// ------------------------------------------------------------------------------------------
+template <int ID> struct Dist;
+
+template <> struct Dist<kHeaviside> {
+    static GENDR_HD float cdf(float sign, float, const DistParams&) { return sign > 0 ? 1.f : 0.f; }   // :251-252
+    static GENDR_HD float pdf(float, float, const DistParams&) { return 0.f; }                          // :375-376
+};
+
+template <> struct Dist<kUniform> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :270-277
+        const float u = sign * x / d.scale;
+        if (u < -1) return 0.f;
+        if (u < 1) return (float)((double)(sign * x) * 0.5 / (double)d.scale + 0.5);
+        return 1.f;
+    }
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :391-392
+        const float u = sign * x / d.scale;
+        return (u > -1 && u < 1) ? 0.5f / d.scale : 0.f;
+    }
+};
+
+template <> struct Dist<kCubicHermite> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :282-290
+        const float u = sign * x / d.scale;
+        if (u < -1) return 0.f;
+        if (u < 1) {
+            const float y = (float)((double)(sign * x) * 0.5 / (double)d.scale + 0.5);
+            return 3 * y * y - 2 * y * y * y;
+        }
+        return 1.f;
+    }
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :397-402
+        const float u = sign * x / d.scale;
+        if (u < -1.f || u > 1.f) return 0.f;
+        return (float)(0.75 / (double)d.scale - 0.75 * (double)(x * x) / pow((double)d.scale, 3.));
+    }
+};
+
+template <> struct Dist<kWigner> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :320-327
+        const float u = sign * x / d.scale;
+        if (u < -1) return 0.f;
+        if (u < 1)
+            return (float)(0.5 + (double)(sign * x * sqrtf(d.scale * d.scale - x * x)) / (kPi * (double)d.scale * (double)d.scale)
+                               + (double)asinf(u) / kPi);
+        return 1.f;
+    }
+    static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :425-427
+        if (x / d.scale > 1) return 0.f;
+        return (float)(2. / kPi / (double)d.scale / (double)d.scale * (double)sqrtf(d.scale * d.scale - x * x));
+    }
+};
+
+template <> struct Dist<kGaussian> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return norm_cdf(sign * x / d.scale); }   // :292-293
+    static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :404-405 (exp in double)
+        const double q = (double)(x / d.scale);
+        return (float)(1. / (double)d.scale / sqrt(2. * kPi) * exp(-0.5 * q * q));
+    }
+};
+
+template <> struct Dist<kLaplace> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :263-268
+        const float e = 0.5f * expf(-x / d.scale);          // 0.5 * e is exact in either precision
+        return sign < 0 ? e : 1.f - e;
+    }
+    static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :388-389
+        return (float)(0.5 / (double)d.scale * (double)expf(-x / d.scale));
+    }
+};
+
+template <> struct Dist<kLogistic> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :254-255
+        return (float)(1. / (1. + (double)expf(-sign * x / d.scale)));
+    }
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :378-380
+        const float y = cdf(sign, x, d);
+        return y * (1 - y) / d.scale;
+    }
+};
+
+template <> struct Dist<kGudermannian> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :279-280
+        return (float)(atan(tanh((double)(sign * x / d.scale) / 2.)) * 2. / kPi + 0.5);
+    }
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :394-395
+        return (float)(1. / (double)coshf(sign * x / d.scale) / kPi / (double)d.scale);
+    }
+};
+
+template <> struct Dist<kCauchy> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :257-258
+        return (float)((double)atanf(sign * x / d.scale) / kPi + 0.5);
+    }
+    static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :382-383
+        return (float)(1. / (kPi * (double)d.scale + kPi / (double)d.scale * (double)x * (double)x));
+    }
+};
+
+template <> struct Dist<kReciprocal> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :260-261
+        return sign * x / d.scale / (1 + x / d.scale) * 0.5f + 0.5f;   // "/2. + 0.5": exact halving, one rounding
+    }
+    static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :385-386
+        const double s = (double)(d.scale + x);
+        return (float)((double)d.scale / (2. * s * s));
+    }
+};
+
+template <> struct Dist<kGumbelMax> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return expf(-expf(-sign * x / d.scale)); }   // :329-331
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :429-430
+        const float u = sign * x / d.scale;
+        return expf(-(u + expf(-u))) / d.scale;
+    }
+};
+
+template <> struct Dist<kGumbelMin> {
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return 1.f - expf(-expf(sign * x / d.scale)); }   // :333-335
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :432-433
+        return expf(-((-sign * x / d.scale) + expf(sign * x / d.scale))) / d.scale;
+    }
+};
+
+template <bool REV> struct ExponentialFamily {                                                           // :349-359, :446-455
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {
+        if (!REV) { if (sign * x + d.shift * d.scale < 0.f) return 0.f; }
+        else      { if (sign * x - d.shift * d.scale > 0.f) return 1.f; }
+        const float xs = shifted<REV>(sign, x, d);
+        const float y = 1.f - expf(-xs / d.scale);
+        return REV ? 1.f - y : y;
+    }
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {
+        if (!REV) { if (sign * x + d.shift * d.scale < 0.f) return 0.f; }
+        else      { if (sign * x - d.shift * d.scale > 0.f) return 0.f; }
+        const float xs = shifted<REV>(sign, x, d);
+        return (float)(1. / (double)d.scale * (double)expf(-xs / d.scale));
+    }
+};
+template <> struct Dist<kExponential> : ExponentialFamily<false> {};
+template <> struct Dist<kExponentialRev> : ExponentialFamily<true> {};
+
+template <bool REV> struct GammaFamily {                                                                 // :295-319, :407-423
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {
+        if (d.shape < 0.f) return quiet_nan();
+        if (!REV) { if (sign * x + d.shift * d.scale <= 0.f) return 0.f; }
+        else      { if (sign * x - d.shift * d.scale >= 0.f) return 1.f; }
+        const float xs = shifted<REV>(sign, x, d);
+        if ((double)(xs / d.scale) > kGammaCut) return REV ? 0.f : 1.f;
+        float kummers = (float)(1. / tgamma((double)d.shape + 1.));
+        float factor = kummers;
+        for (int i = 1; i < kGammaSteps; i++) {              // 32-term Kummer series, float
+            factor *= xs / d.scale / (d.shape + i);
+            kummers += factor;
+        }
+        const float y = powf(xs / d.scale, d.shape) * expf(-xs / d.scale) * kummers;
+        return REV ? 1.f - y : y;
+    }
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // explicit double in the reference
+        if (d.shape < 0.f) return quiet_nan();
+        double xs;
+        if (!REV) {
+            if (sign * x + d.shift * d.scale <= 0.f) return 0.f;
+            xs = (double)sign * (double)x + (double)d.shift * (double)d.scale;
+        } else {
+            if (sign * x - d.shift * d.scale >= 0.f) return 0.f;
+            xs = -((double)sign * (double)x - (double)d.shift * (double)d.scale);
+        }
+        return (float)(pow(1. / (double)d.scale, (double)d.shape) / tgamma((double)d.shape)
+                       * pow(xs, (double)d.shape - 1.) * exp(-xs / (double)d.scale));
+    }
+};
+template <> struct Dist<kGamma> : GammaFamily<false> {};
+template <> struct Dist<kGammaRev> : GammaFamily<true> {};
+
+template <bool REV> struct LevyFamily {                                                                  // :337-347, :435-444
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) {
+        if (!REV) { if ((double)(sign * x + d.shift * d.scale) <= 1e-6) return 0.f; }
+        else      { if ((double)(sign * x - d.shift * d.scale) >= -1e-6) return 1.f; }
+        const float xs = shifted<REV>(sign, x, d);
+        const float y = (float)erfc(sqrt((double)d.scale / 2. / (double)xs));
+        return REV ? 1.f - y : y;
+    }
+    static GENDR_HD float pdf(float sign, float x, const DistParams& d) {
+        if (!REV) { if ((double)(sign * x + d.shift * d.scale) <= 1e-6) return 0.f; }
+        else      { if ((double)(sign * x - d.shift * d.scale) >= -1e-6) return 0.f; }
+        const float xs = shifted<REV>(sign, x, d);
+        return (float)(sqrt((double)d.scale / 2. / kPi) * exp((double)(-d.scale) / 2. / (double)xs) / pow((double)xs, 1.5));
+    }
+};
+template <> struct Dist<kLevy> : LevyFamily<false> {};
+template <> struct Dist<kLevyRev> : LevyFamily<true> {};
+
+#define GENDR_FOR_EACH_DIST(X) \
+    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)
+
+GENDR_HD float cdf_rt(int id, float sign, float x, const DistParams& d)
+{
+    switch (id) {
+#define X(i) case i: return Dist<i>::cdf(sign, x, d);
+        GENDR_FOR_EACH_DIST(X)
+#undef X
+        default: return quiet_nan();
+    }
+}
+GENDR_HD float pdf_rt(int id, float sign, float x, const DistParams& d)
+{
+    switch (id) {
+#define X(i) case i: return Dist<i>::pdf(sign, x, d);
+        GENDR_FOR_EACH_DIST(X)
+#undef X
+        default: return quiet_nan();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// t-conorms.  fold(a, b, p): alpha <- T(alpha, D_f) (kernel.cu:474-563);
+// grad(A, b, p): d alpha_final / d D_f from the final alpha A (kernel.cu:567-614).
+// ------------------------------------------------------------------------------------------
+template <int ID> struct TConorm;
+
+template <> struct TConorm<kMax> {
+    static GENDR_HD float fold(float a, float b, float) { return fmaxf(a, b); }                          // :481-482
+    static GENDR_HD float grad(float A, float b, float) { return A == b ? 1.f : 0.f; }                   // :574-575
+};
+template <> struct TConorm<kProbabilistic> {
+    static GENDR_HD float fold(float a, float b, float) { return a + b - a * b; }                        // :484-485
+    static GENDR_HD float grad(float A, float b, float) {                                                // :577-578
+        return (float)((1. - (double)A) / fmax(1. - (double)b, 1e-6));
+    }
+};
+template <> struct TConorm<kEinstein> {
+    static GENDR_HD float fold(float a, float b, float) { return (a + b) / (1 + a * b); }                // :487-488
+    static GENDR_HD float grad(float A, float b, float) {                                                // :580-581
+        return (float)((1. - (double)(A * A)) / fmax(1. - (double)(b * b), 1e-6));
+    }
+};
+template <> struct TConorm<kHamacher> {
+    static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :490-498
+        if (p < 0.f) return quiet_nan();
+        const float a = 1.f - a_ex, b = 1.f - b_new;
+        const float c = (float)((double)(a * b) / fmax((double)p + (1. - (double)p) * (double)(a + b - a * b), 1e-6));
+        return 1.f - c;
+    }
+    static GENDR_HD float grad(float A_, float b_, float p_) {                                           // :583-584
+        const double A = A_, b = b_, p = p_;
+        return (float)((1.0 - A) * (-A - p * (1.0 - A) + p + 1.0) / fmax((1.0 - b) * (-b - p * (1.0 - b) + p + 1.0), 1e-6));
+    }
+};
+template <> struct TConorm<kFrank> {
+    static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :500-509
+        if (p <= 0.f || p == 1.f) return quiet_nan();
+        const float a = 1.f - a_ex, b = 1.f - b_new;
+        const float c = (float)(log1p(((double)powf(p, a) - 1.) * ((double)powf(p, b) - 1.) / ((double)p - 1.)) / (double)logf(p));
+        return 1.f - c;
+    }
+    static GENDR_HD float grad(float A, float b, float p) {                                              // :586-588
+        const float d = (float)(pow((double)p, 1.0 - (double)b) - 1.0);
+        return (float)((double)powf(p, A - b) * (pow((double)p, 1.0 - (double)A) - 1.0) / ((double)d + copysign(1e-6, (double)d)));
+    }
+};
+template <> struct TConorm<kYager> {
+    static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :511-519
+        if (p <= 0.f) return quiet_nan();
+        const float a = 1.f - a_ex, b = 1.f - b_new;
+        const float c = (float)fmax(0., 1. - pow(pow(1. - (double)a, (double)p) + pow(1. - (double)b, (double)p), 1. / (double)p));
+        return 1.f - c;
+    }
+    static GENDR_HD float grad(float A, float b, float p) {                                              // :590-592
+        if (A == 1.f) return 0.f;
+        return (float)(pow((double)b, (double)p - 1.) * pow((double)A, 1. - (double)p));
+    }
+};
+template <> struct TConorm<kAczelAlsina> {
+    static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :521-531
+        if (p <= 0.f) return quiet_nan();
+        const float a = 1.f - a_ex, b = 1.f - b_new;
+        if ((double)a < 1e-8 || (double)b < 1e-8) return 1.f;
+        const float c = (float)exp(-pow((double)(powf(-logf(a), p) + powf(-logf(b), p)), 1. / (double)p));
+        return 1.f - c;
+    }
+    static GENDR_HD float grad(float A_, float b_, float p_) {                                           // :594-598
+        const double A = A_, b = b_, p = p_;
+        return (float)((1. - A) * pow(-log1p(fmax(-b, -1. + 1e-6)), p - 1.) * pow(-log1p(fmax(-A, -1. + 1e-6)), 1. - p)
+                       / fmax(1. - b, 1e-6));
+    }
+};
+template <> struct TConorm<kDombi> {
+    static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :533-549
+        if (p <= 0.f) return quiet_nan();
+        const float a = 1.f - a_ex, b = 1.f - b_new;
+        if ((double)a < 1e-8 || (double)b < 1e-8) return 1.f;
+        const float c = (float)(1. / (1. + pow(pow((1. - (double)a) / (double)a, (double)p)
+                                               + pow((1. - (double)b) / (double)b, (double)p), 1. / (double)p)));
+        return 1.f - c;
+    }
+    static GENDR_HD float grad(float A_, float b_, float p_) {                                           // :600-604
+        const double A = A_, b = b_, p = p_;
+        return (float)((1. - A) * (1. - A) * pow(b / fmax(1. - b, 1e-6), p - 1.) * pow(A / fmax(1. - A, 1e-6), 1. - p)
+                       / fmax(1. - b, 1e-6) / fmax(1. - b, 1e-6));
+    }
+};
+template <> struct TConorm<kSchweizerSklar> {
+    static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :551-559
+        if (p >= 0.f) return quiet_nan();
+        const float a = 1.f - a_ex, b = 1.f - b_new;
+        const float c = (float)pow((double)(powf(a, p) + powf(b, p)) - 1., 1. / (double)p);
+        return 1.f - c;
+    }
+    static GENDR_HD float grad(float A, float b, float p) {                                              // :606-610
+        const float a1 = (float)fmax(1. - (double)A, 1e-6);
+        const float b1 = (float)fmax(1. - (double)b, 1e-6);
+        const double pd = p;
+        return (float)(pow((double)b1, pd - 1.)
+                       * pow((double)powf(b1, p) + pow(pow((double)(-powf(b1, p) + powf(a1, p)) + 1., 1. / pd), pd) - 1., (1. - pd) / pd));
+    }
+};
+
+#define GENDR_FOR_EACH_TCONORM(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+
+GENDR_HD float tconorm_fold_rt(int id, float a, float b, float p)
+{
+    switch (id) {
+#define X(i) case i: return TConorm<i>::fold(a, b, p);
+        GENDR_FOR_EACH_TCONORM(X)
+#undef X
+        default: return quiet_nan();
+    }
+}
+GENDR_HD float tconorm_grad_rt(int id, float A, float b, float p)
+{
+    switch (id) {
+#define X(i) case i: return TConorm<i>::grad(A, b, p);
+        GENDR_FOR_EACH_TCONORM(X)
+#undef X
+        default: return quiet_nan();
+    }
+}
+
+}  // namespace gendr

@@ -1,0 +1,120 @@
+/*
+ * gendr_hip.h -- C ABI of libgendr_hip.so, the MI355X (gfx950) generalized soft
+ * rasterizer.  This is the drop-in boundary for the one hot path of
+ * Felix-Petersen/gendr: what the reference binds through pybind11 in
+ * gendr/cuda/generalized_renderer_cuda.cpp:230-237 (module
+ * `gendr.cuda.generalized_renderer`).  Plain pointers and sizes, no torch
+ * types.  All device pointers are fp32, contiguous, and owned by the caller;
+ * nothing is allocated inside, every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*), there is no global state.
+ *
+ * Return value of every int function: 0 on success, a negative GENDR_E_* code
+ * otherwise (never print-and-continue as kernel.cu:1111-1113 does).
+ */
+#ifndef GENDR_HIP_H
+#define GENDR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENDR_ABI_VERSION 1
+
+enum {
+    GENDR_OK              = 0,
+    GENDR_E_NULL          = -1,  /* a required pointer is NULL */
+    GENDR_E_SHAPE         = -2,  /* B, nf, T or image_size out of range */
+    GENDR_E_DIST_FUNC     = -3,  /* dist_func not in 0..17 (kernel.cu:361) */
+    GENDR_E_ALPHA_FUNC    = -4,  /* aggr_alpha_func not in 0..9 (kernel.cu:561) */
+    GENDR_E_RGB_FUNC      = -5,  /* aggr_rgb_func not in {0,1} */
+    GENDR_E_TEXTURE_TYPE  = -6,  /* texture_type not in {0,1}, or T inconsistent with it */
+    GENDR_E_DIST_PARAM    = -7,  /* dist_scale < 0, dist_eps < 1 (functional/renderer.py:96,101), gamma shape < 0 (kernel.cu:296) */
+    GENDR_E_TCONORM_PARAM = -8,  /* invalid t-conorm p (kernel.cu:491,501,512,522,534,552) */
+    GENDR_E_LAUNCH        = -9,  /* hipGetLastError() != hipSuccess after a launch */
+    GENDR_E_WORKSPACE     = -10  /* face_records buffer missing */
+};
+
+/* Scalar options of forward_render / backward_render, in the reference's order
+ * (generalized_renderer_cuda.cpp:80-96, kernel.cu:1077-1092).  `near`/`far`
+ * carry a trailing underscore only because <windows.h>-style macros exist. */
+typedef struct gendr_params {
+    int   image_size;              /* internal size (already doubled for anti-aliasing, gendr/renderer.py:68) */
+    int   dist_func;               /* 0..17 */
+    float dist_scale;              /* tau */
+    int   dist_squared;
+    float dist_shape;
+    float dist_shift;
+    float dist_eps;
+    int   aggr_alpha_func;         /* 0..9 */
+    float aggr_alpha_t_conorm_p;
+    int   aggr_rgb_func;           /* 0 hard, 1 softmax */
+    float aggr_rgb_eps;
+    float aggr_rgb_gamma;
+    float near_;
+    float far_;
+    int   double_side;
+    int   texture_type;            /* 0 surface (T = R*R texels), 1 vertex (T = 3) */
+    /* ---- additions of this ABI (no reference counterpart) ---- */
+    float background[3];           /* used when background_from_buffer == 0 */
+    int   background_from_buffer;  /* 1: rgba planes 0..2 arrive pre-filled with the background,
+                                      as functional/renderer.py:144-151 hands them to forward_render */
+    int   texel_mode;              /* 0: reference-faithful surface texel index (kernel.cu:179-184 may
+                                         index the following face's texels); 1: clamp to the face's own block */
+    int   cull;                    /* 1: exact tile culling (default), 0: visit every (pixel, face) pair */
+} gendr_params;
+
+/* Floats per face in the face-record workspace (depends on the texture layout). */
+int gendr_face_record_floats(int texture_type, int T);
+
+/* Validates the option set exactly as the reference's asserts / device checks do. */
+int gendr_validate(const gendr_params* p, int B, int nf, int T);
+
+/* Per-face preprocessing into this build's record layout (replaces forward_render_inv_cuda_kernel,
+ * kernel.cu:620-676, launched at :1100-1109).  gendr_forward() runs it itself; it is exported for
+ * callers that hold only `faces` when they reach backward (the pybind-shaped backward_render).
+ *   face_records [B*nf, gendr_face_record_floats()] out */
+int gendr_face_setup(const float* faces, const float* textures, float* face_records,
+                     int B, int nf, int T, const gendr_params* p, void* stream);
+
+/* replaces forward_render (generalized_renderer_cuda.cpp:74-127 -> kernel.cu:1071-1152).
+ *   faces        [B,nf,9]    in   (x,y,z per vertex, NDC)
+ *   textures     [B,nf,T,3]  in
+ *   rgba         [B,4,is,is] out  (in/out when background_from_buffer)   = `soft_colors`
+ *   aggrs_info   [B,2,is,is] out  (softmax_sum, softmax_max) or (depth_min, face_index_min)
+ *   face_records [B,nf,gendr_face_record_floats()] out, workspace kept for backward
+ *                (this build's replacement for `faces_info`). */
+int gendr_forward(const float* faces, const float* textures, float* rgba, float* aggrs_info,
+                  float* face_records, int B, int nf, int T, const gendr_params* p, void* stream);
+
+/* replaces backward_render (generalized_renderer_cuda.cpp:130-192 -> kernel.cu:1155-1227).
+ *   grad_faces [B,nf,9] and grad_textures [B,nf,T,3] must be zero-filled by the
+ *   caller (functional/renderer.py:191-196); gradients are accumulated into them. */
+int gendr_backward(const float* faces, const float* textures, const float* rgba, const float* aggrs_info,
+                   const float* face_records, const float* grad_rgba,
+                   float* grad_faces, float* grad_textures,
+                   int B, int nf, int T, const gendr_params* p, void* stream);
+
+/* The reference's per-face preprocessing in its own layout, faces_info [B,nf,27] =
+ * inv[9], sym[9], obt[3], 0[6] (kernel.cu:620-676, functional/renderer.py:139), for
+ * callers of the pybind-shaped forward_render that inspect faces_info. */
+int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* stream);
+
+/* replace sigmoid_forward/backward, t_conorm_forward/backward
+ * (generalized_renderer_cuda.cpp:195-227,233-236; kernel.cu:1230-1270): host-callable scalars. */
+float gendr_sigmoid_forward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift);
+float gendr_sigmoid_backward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift);
+float gendr_t_conorm_forward(int t_conorm_id, float a_existing, float b_new, int face_id, float t_conorm_p);
+float gendr_t_conorm_backward(int t_conorm_id, float a_all, float b_current, int number_of_faces, float t_conorm_p);
+
+/* Distance (in NDC units) beyond which an outside pixel provably contributes nothing
+ * (D <= 1e-6, kernel.cu:784, or d^2 >= dist_eps*tau, kernel.cu:769); +inf if no such
+ * distance exists for the option set.  Used by the face-setup kernel. */
+float gendr_cull_radius(const gendr_params* p);
+
+const char* gendr_error_string(int code);
+int gendr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

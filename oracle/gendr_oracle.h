@@ -1,0 +1,115 @@
+/*
+ * gendr_oracle.h -- CPU oracle for the generalized soft rasterizer hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under gendr_amd/ may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (Felix-Petersen/gendr) ships no tests, golden
+ * vectors or fixtures for this path, and its only implementation is CUDA
+ * (gendr/cuda/generalized_renderer_cuda_kernel.cu) which cannot be built in
+ * this image without writing stand-in CUDA headers / runtime.  This file is a
+ * restatement of that kernel's published arithmetic, written from the source
+ * text, citing the lines it follows ("kernel.cu:N").  What pins it instead is
+ * listed in DESIGN.md (closed-form CDF/pdf checks against scipy, finite
+ * differences of the fp64 build, a second independent restatement in
+ * PyTorch).
+ *
+ * Two instantiations exist, mirroring AT_DISPATCH_FLOATING_TYPES
+ * (kernel.cu:1102,1117,1189): *_f32 follows the float instantiation including
+ * its float<->double promotions expression by expression (double literals such
+ * as `1.`, `0.5`, `1e-6`, M_PI promote the sub-expression they appear in);
+ * *_f64 is the double instantiation.
+ */
+#ifndef GENDR_ORACLE_H
+#define GENDR_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors the scalar argument list of forward_render / backward_render
+ * (generalized_renderer_cuda.cpp:74-96,130-155).  Scalars are `float` exactly
+ * as in the reference launcher signature (kernel.cu:1077-1092), also for the
+ * double instantiation. */
+typedef struct {
+    int   image_size;
+    int   dist_func;              /* 0..17, kernel.cu:217-239 */
+    float dist_scale;
+    int   dist_squared;
+    float dist_shape;
+    float dist_shift;
+    float dist_eps;
+    int   aggr_alpha_func;        /* 0..9, kernel.cu:462-470 */
+    float aggr_alpha_t_conorm_p;
+    int   aggr_rgb_func;          /* 0 hard, 1 softmax */
+    float aggr_rgb_eps;
+    float aggr_rgb_gamma;
+    float near_;
+    float far_;
+    int   double_side;
+    int   texture_type;           /* 0 surface, 1 vertex */
+    /* Decisions where the reference is undefined (DESIGN.md "reference quirks"):
+     * texel_mode 0 = reference-faithful surface texel index (may run into the
+     *                following face's texels, kernel.cu:179-184); reads past the
+     *                end of the whole tensor are clamped to the face's own
+     *                last texel instead of reading the heap;
+     *            1 = clamp the texel index to the face's own R x R block. */
+    int   texel_mode;
+    int   num_threads;            /* OpenMP threads; <=0 -> runtime default */
+} gendr_oracle_opts;
+
+/* scalar functions, float instantiation (kernel.cu:1230-1270) */
+float gendr_oracle_sigmoid_forward(int id, float sign, float x, float scale, float shape, float shift);
+float gendr_oracle_sigmoid_backward(int id, float sign, float x, float scale, float shape, float shift);
+float gendr_oracle_t_conorm_forward(int id, float a_existing, float b_new, int face_id, float p);
+float gendr_oracle_t_conorm_backward(int id, float a_all, float b_current, int nf, float p);
+/* double instantiation of the same templates */
+double gendr_oracle_sigmoid_forward_f64(int id, double sign, double x, double scale, double shape, double shift);
+double gendr_oracle_sigmoid_backward_f64(int id, double sign, double x, double scale, double shape, double shift);
+double gendr_oracle_t_conorm_forward_f64(int id, double a_existing, double b_new, int face_id, double p);
+double gendr_oracle_t_conorm_backward_f64(int id, double a_all, double b_current, int nf, double p);
+
+/* faces [B,nf,9] -> faces_info [B,nf,27] (kernel.cu:620-676).  faces_info must
+ * be zero-filled by the caller (functional/renderer.py:136). */
+void gendr_oracle_face_info_f32(const float* faces, float* faces_info, int B, int nf);
+void gendr_oracle_face_info_f64(const double* faces, double* faces_info, int B, int nf);
+
+/* forward (kernel.cu:680-862).  soft_colors [B,4,is,is] must arrive pre-filled
+ * with the background colour in planes 0..2 (functional/renderer.py:144-151);
+ * aggrs_info [B,2,is,is] is written. */
+void gendr_oracle_forward_f32(const float* faces, const float* textures, const float* faces_info,
+                              float* aggrs_info, float* soft_colors,
+                              int B, int nf, int T, const gendr_oracle_opts* o);
+void gendr_oracle_forward_f64(const double* faces, const double* textures, const double* faces_info,
+                              double* aggrs_info, double* soft_colors,
+                              int B, int nf, int T, const gendr_oracle_opts* o);
+
+/* backward (kernel.cu:866-1065).  grad_faces [B,nf,9], grad_textures
+ * [B,nf,T,3] are overwritten.  Per-pair contributions are computed in the
+ * instantiation's type exactly as the reference does, but summed in double
+ * (the reference's atomicAdd order is unspecified).  abs_faces / abs_textures
+ * (may be NULL) receive sum |contribution| per element, for
+ * conditioning-aware tolerances. */
+void gendr_oracle_backward_f32(const float* faces, const float* textures, const float* soft_colors,
+                               const float* faces_info, const float* aggrs_info,
+                               float* grad_faces, float* grad_textures, const float* grad_soft_colors,
+                               float* abs_faces, float* abs_textures,
+                               int B, int nf, int T, const gendr_oracle_opts* o);
+void gendr_oracle_backward_f64(const double* faces, const double* textures, const double* soft_colors,
+                               const double* faces_info, const double* aggrs_info,
+                               double* grad_faces, double* grad_textures, const double* grad_soft_colors,
+                               double* abs_faces, double* abs_textures,
+                               int B, int nf, int T, const gendr_oracle_opts* o);
+
+/* number of (pixel, face) pairs that survive all three skip tests in the
+ * forward loop (kernel.cu:747,769,784) -- used to size the culling report. */
+long long gendr_oracle_count_pairs_f32(const float* faces, const float* faces_info,
+                                       int B, int nf, const gendr_oracle_opts* o);
+
+int gendr_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""HIP path (through the C ABI) vs the CPU oracle on the same inputs: shared by the -m gpu tests,
+__graft_entry__.smoke() and the parity report.  Test infrastructure."""
+import numpy as np
+import torch
+
+import oracle
+from gendr_amd.functional import renderer as R
+
+RENDER_KEYS = ('dist_func', 'dist_scale', 'dist_squared', 'dist_shape', 'dist_shift', 'dist_eps',
+               'aggr_alpha_func', 'aggr_alpha_t_conorm_p', 'aggr_rgb_func', 'aggr_rgb_eps', 'aggr_rgb_gamma',
+               'near', 'far', 'double_side', 'texture_type')
+DEFAULTS = dict(dist_func='uniform', dist_scale=1e-2, dist_squared=False, dist_shape=None, dist_shift=None,
+                dist_eps=1e4, aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=None, aggr_rgb_func='softmax',
+                aggr_rgb_eps=1e-3, aggr_rgb_gamma=1e-3, near=1, far=100, double_side=True, texture_type='surface')
+
+
+def split_options(opts):
+    o = dict(DEFAULTS)
+    extra = dict(background=(0., 0., 0.), texel_mode=0, T=1, cull=1)
+    for k, v in opts.items():
+        if k in extra:
+            extra[k] = v
+        else:
+            o[k] = v
+    return o, extra
+
+
+def hip_params(image_size, o, extra):
+    p = R.make_params(image_size, list(extra['background']), *[o[k] for k in RENDER_KEYS])
+    p.texel_mode = extra['texel_mode']
+    p.cull = extra['cull']
+    return p
+
+
+def run_hip(fv, tex, image_size, opts, grad=None, device='cuda:0'):
+    """fv [B,nf,3,3], tex [B,nf,T,3] numpy.  Returns dict of numpy arrays."""
+    o, extra = split_options(opts)
+    p = hip_params(image_size, o, extra)
+    B, nf = fv.shape[:2]
+    faces = torch.from_numpy(np.ascontiguousarray(fv, np.float32)).reshape(B, nf, 9).to(device)
+    textures = torch.from_numpy(np.ascontiguousarray(tex, np.float32)).to(device)
+    rgba, aux, rec = R.native_forward(faces, textures, p)
+    out = dict(rgba=rgba.cpu().numpy(), aggrs_info=aux.cpu().numpy())
+    if grad is not None:
+        g = torch.from_numpy(np.ascontiguousarray(grad, np.float32)).to(device)
+        gf, gt = R.native_backward(faces, textures, rgba, aux, rec, g, p)
+        out['grad_faces'] = gf.cpu().numpy()
+        out['grad_textures'] = gt.cpu().numpy()
+    torch.cuda.synchronize()
+    return out
+
+
+def run_oracle(fv, tex, image_size, opts, grad=None, dtype=np.float32, threads=0):
+    o, extra = split_options(opts)
+    oo = oracle.make_opts(image_size=image_size, texel_mode=extra['texel_mode'], num_threads=threads, **o)
+    fwd = oracle.forward(fv, tex, oo, background=extra['background'], dtype=dtype)
+    out = dict(rgba=fwd['rgba'], aggrs_info=fwd['aggrs_info'], faces_info=fwd['faces_info'])
+    if grad is not None:
+        gf, gt, af, at = oracle.backward(fwd, grad, oo, dtype=dtype)
+        out.update(grad_faces=gf, grad_textures=gt, abs_faces=af, abs_textures=at)
+    return out
+
+
+def stats(got, ref, scale=None):
+    """max abs error, max / p99 relative error with the denominator floored at 1e-6 * max|ref|
+    (or at `scale`, e.g. the sum of |contributions| of a gradient element), fraction above 1e-5."""
+    got = np.asarray(got, np.float64).ravel()
+    ref = np.asarray(ref, np.float64).ravel()
+    if ref.size == 0:
+        return dict(max_abs=0.0, max_rel=0.0, p99_rel=0.0, frac_gt_1e5=0.0, exact=1.0, n=0)
+    d = np.abs(got - ref)
+    d = np.where(np.isnan(got) & np.isnan(ref), 0.0, d)
+    floor = 1e-6 * (np.nanmax(np.abs(ref)) if np.isfinite(np.nanmax(np.abs(ref))) else 1.0)
+    den = np.maximum(np.abs(ref), floor)
+    if scale is not None:
+        den = np.maximum(den, np.asarray(scale, np.float64).ravel())
+    rel = d / np.maximum(den, 1e-300)
+    rel = np.where(np.isnan(rel), np.inf, rel)
+    return dict(max_abs=float(np.nanmax(d)), max_rel=float(rel.max()), p99_rel=float(np.percentile(rel, 99)),
+                frac_gt_1e5=float((rel > 1e-5).mean()), exact=float((got == ref).mean()), n=int(ref.size))
+
+
+def compare(fv, tex, image_size, opts, seed=1, with_grad=True):
+    rs = np.random.RandomState(seed)
+    B = fv.shape[0]
+    grad = rs.randn(B, 4, image_size, image_size).astype(np.float32) if with_grad else None
+    h = run_hip(fv, tex, image_size, opts, grad)
+    r = run_oracle(fv, tex, image_size, opts, grad)
+    res = dict(rgba=stats(h['rgba'], r['rgba']), alpha=stats(h['rgba'][:, 3], r['rgba'][:, 3]),
+               aggrs=stats(h['aggrs_info'], r['aggrs_info']))
+    if with_grad:
+        res['grad_faces'] = stats(h['grad_faces'], r['grad_faces'])
+        res['grad_textures'] = stats(h['grad_textures'], r['grad_textures'])
+        # conditioning-aware: error relative to the sum of |contributions| of each element
+        res['grad_faces_cond'] = stats(h['grad_faces'], r['grad_faces'], scale=r['abs_faces'])
+        res['grad_textures_cond'] = stats(h['grad_textures'], r['grad_textures'], scale=r['abs_textures'])
+    return res, h, r
+
+
+def fmt(name, res):
+    parts = []
+    for k, s in res.items():
+        parts.append('%s[max_rel=%.2e p99=%.1e >1e-5:%.2e exact=%.3f]' % (k, s['max_rel'], s['p99_rel'], s['frac_gt_1e5'], s['exact']))
+    return '%-26s ' % name + ' '.join(parts)
