@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark: generalized soft rasterizer forward + backward, frames/s.
+
+Workload (BASELINE.json configs[1], "C2"): synthetic 1280-face mesh, 256x256, batch 64 per GPU,
+dist_func=uniform, aggr_alpha_func=probabilistic, aggr_rgb_func=softmax, tau=1e-2, library defaults
+otherwise.  A step = one forward and one backward of the autograd Function (`gendr_amd.functional.render`)
+on inputs already resident in HBM.  Multi-GPU: one process per GPU (torch.distributed, RCCL), the batch
+axis is sharded, no collective on the data path, weak scaling (64 frames per GPU).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline":     algorithmic HBM bytes of the dominant kernel / its measured average duration vs 8 TB/s
+  "cpu_baseline": the CPU oracle (C port of the reference arithmetic, OpenMP) timed on this box's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6290 GB/s measured achievable
+
+CONFIGS = {
+    # name: (batch per GPU, subdivisions, image_size, render options, texture)
+    'c2': dict(batch=64, subdiv=3, image_size=256, texture='surface',
+               opts=dict(dist_func='uniform', dist_scale=1e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax')),
+    'c3': dict(batch=64, subdiv=3, image_size=256, texture='surface',
+               opts=dict(dist_func='gaussian', dist_scale=1e-4, dist_squared=True, aggr_alpha_func='einstein', aggr_rgb_func='softmax')),
+    'c4': dict(batch=32, subdiv=3, image_size=512, texture='surface',
+               opts=dict(dist_func='logistic', dist_scale=1e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax')),
+    'c5': dict(batch=8, subdiv=3, image_size=2048, texture='vertex',
+               opts=dict(dist_func='gamma', dist_shape=2.0, dist_scale=1e-2, aggr_alpha_func='yager', aggr_alpha_t_conorm_p=2.0,
+                         aggr_rgb_func='softmax', texture_type='vertex')),
+}
+
+
+def algorithmic_bytes(P, nf, T):
+    """every tensor crossing the Function boundary touched once.
+    forward: read faces 36 nf + textures 12 T nf, write RGBA 16 P;
+    backward: read faces + textures again, RGBA 16 P, grad RGBA 16 P, write grad_faces 36 nf + grad_textures 12 T nf."""
+    per_face = 36 + 12 * T
+    fwd = 16 * P + per_face * nf
+    bwd = 32 * P + 2 * per_face * nf
+    return fwd, bwd
+
+
+def cpu_baseline(cfg, fv, tex, target_seconds=15.0):
+    """Times the CPU oracle (oracle/, test infrastructure used here only as the reported baseline)
+    on a bounded sample of the same workload with all host cores."""
+    import numpy as np
+    import oracle
+    oracle.build()
+    isz = cfg['image_size']
+    opts = dict(cfg['opts'])
+    opts.setdefault('double_side', False)
+    oo = oracle.make_opts(image_size=isz, **opts)
+    cores = oracle.max_threads()
+    fvn = fv.cpu().numpy()
+    texn = tex.cpu().numpy()
+    rs = np.random.RandomState(1)
+
+    def run(n):
+        g = rs.randn(n, 4, isz, isz).astype(np.float32)
+        t0 = time.perf_counter()
+        fwd = oracle.forward(fvn[:n], texn[:n], oo)
+        oracle.backward(fwd, g, oo)
+        return time.perf_counter() - t0
+
+    t1 = run(1)
+    n = int(max(1, min(fvn.shape[0], target_seconds / max(t1, 1e-3))))
+    tn = run(n) if n > 1 else t1
+    return dict(value=n / tn, unit='frames/s', cores=cores, kind='port',
+                sample='%d frame(s) of the same workload (%dx%d, %d faces), forward+backward, C oracle with OpenMP on %d threads, %.1f s'
+                       % (n, isz, isz, fvn.shape[1], cores, tn))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='frames per GPU (default: the config\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cull', action='store_true', help='visit every (pixel, face) pair (diagnostic)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.no_cull:
+        os.environ['GENDR_CULL'] = '0'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from gendr_amd import build
+    build.build()
+    from gendr_amd.functional import renderer as R
+    from gendr_amd.synthetic import benchmark_scene
+
+    cfg = dict(CONFIGS[args.config])
+    B = args.batch or cfg['batch']
+    isz = cfg['image_size']
+    opts = dict(cfg['opts'])
+    opts.setdefault('double_side', False)          # gendr.GenDR() default (gendr/renderer.py:34)
+    # each rank renders its own shard of views: distinct cameras per rank
+    fv_all, tex_all = benchmark_scene(B * world, subdivisions=cfg['subdiv'], texture=cfg['texture'], seed=0)
+    fv = fv_all[rank * B:(rank + 1) * B].to(dev).requires_grad_(True)
+    tex = tex_all[rank * B:(rank + 1) * B].to(dev).requires_grad_(True)
+    nf, T = fv.shape[1], tex.shape[2]
+    g = torch.Generator(device='cpu').manual_seed(1 + rank)
+    grad = torch.randn(B, 4, isz, isz, generator=g).to(dev)
+
+    events = []
+
+    def step(record):
+        fv.grad = None
+        tex.grad = None
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            R.PROFILE_EVENTS = e
+        img = R.render(fv, tex, image_size=isz, **opts)
+        img.backward(grad)
+        if record:
+            events.append(e)
+            R.PROFILE_EVENTS = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations from the HIP events recorded on the launch stream around the native calls
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
+    bwd_ms = sum(e[2].elapsed_time(e[3]) for e in events) / len(events)
+
+    if rank == 0:
+        P = isz * isz
+        fwd_b, bwd_b = algorithmic_bytes(P, nf, T)
+        dom = 'render_backward_kernel' if bwd_ms >= fwd_ms else 'face_setup_kernel+render_forward_kernel'
+        dom_bytes = (bwd_b if bwd_ms >= fwd_ms else fwd_b) * B
+        dom_ms = max(bwd_ms, fwd_ms)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.config)
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch', {}).get(dom.split('+')[-1])
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'soft_rasterize fwd+bwd frames/s @%d^2, %d faces, batch %d per GPU' % (isz, nf, B),
+            'value': world * B * args.steps / elapsed,
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': '%s: %d-face icosphere variant, %dx%d, %s, batch %d per GPU, T=%d, double_side=%s, dist_eps=1e4'
+                                   % (args.config.upper(), nf, isz, isz,
+                                      '/'.join(str(opts[k]) for k in ('dist_func', 'aggr_alpha_func', 'aggr_rgb_func')),
+                                      B, T, opts['double_side']),
+                       'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
+                       'cull': os.environ.get('GENDR_CULL', '1') != '0'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
+                         'note': 'VALU-bound path (SURVEY.md H2); whole-op fraction = %.4f'
+                                 % ((fwd_b + bwd_b) * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS)},
+            'kernel_ms': {'forward_phase': fwd_ms, 'backward_phase': bwd_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, fv_all[:B], tex_all[:B])
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -57,6 +57,10 @@ TEXTURE_TYPE_IDS = {'surface': 0, 'vertex': 1}
 
 _TEXEL_MODES = {'reference': 0, 'clamp': 1}
 
+# bench.py sets this to four torch.cuda.Event objects to time the native forward / backward calls with HIP
+# events on the launch stream: [fwd start, fwd end, bwd start, bwd end].  None = no timing.
+PROFILE_EVENTS = None
+
 
 def _lookup(value, table, what):
     if isinstance(value, bool):
@@ -141,9 +145,14 @@ def native_forward(faces, textures, params, rgba=None, aggrs_info=None):
         aggrs_info = torch.empty((B, 2, isz, isz), dtype=torch.float32, device=dev)
     rec_floats = L.gendr_face_record_floats(params.texture_type, T)
     records = torch.empty((max(B * nf, 1), rec_floats), dtype=torch.float32, device=dev)
+    ev = PROFILE_EVENTS
     with torch.cuda.device(dev):
+        if ev is not None:
+            ev[0].record()
         check(L.gendr_forward(_ptr(faces), _ptr(textures), _ptr(rgba), _ptr(aggrs_info), _ptr(records),
                               B, nf, T, ctypes.byref(params), _stream_ptr()), 'gendr_forward')
+        if ev is not None:
+            ev[1].record()
     return rgba, aggrs_info, records
 
 
@@ -156,10 +165,15 @@ def native_backward(faces, textures, rgba, aggrs_info, records, grad_rgba, param
         grad_faces = torch.zeros((B, nf, 9), dtype=torch.float32, device=dev)
     if grad_textures is None:
         grad_textures = torch.zeros(textures.shape, dtype=torch.float32, device=dev)
+    ev = PROFILE_EVENTS
     with torch.cuda.device(dev):
+        if ev is not None:
+            ev[2].record()
         check(L.gendr_backward(_ptr(faces), _ptr(textures), _ptr(rgba), _ptr(aggrs_info), _ptr(records),
                                _ptr(grad_rgba), _ptr(grad_faces), _ptr(grad_textures),
                                B, nf, T, ctypes.byref(params), _stream_ptr()), 'gendr_backward')
+        if ev is not None:
+            ev[3].record()
     return grad_faces, grad_textures
 
 
