@@ -41,7 +41,7 @@ class GendrParams(ctypes.Structure):
 
 
 EXPORTS = (
-    "gendr_abi_version", "gendr_error_string", "gendr_face_record_floats", "gendr_validate",
+    "gendr_abi_version", "gendr_params_size", "gendr_error_string", "gendr_face_record_floats", "gendr_validate",
     "gendr_face_setup", "gendr_forward", "gendr_backward", "gendr_face_info",
     "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
     "gendr_cull_radius",
@@ -93,6 +93,11 @@ def lib():
         getattr(L, name).argtypes = [i, f, f, i, f]
     L.gendr_cull_radius.restype = f
     L.gendr_cull_radius.argtypes = [pp]
+    L.gendr_params_size.restype = i
+    L.gendr_params_size.argtypes = []
+    if L.gendr_params_size() != ctypes.sizeof(GendrParams):
+        raise NativeLibraryError("gendr_amd: gendr_params layout mismatch (library %d bytes, python %d bytes)"
+                                 % (L.gendr_params_size(), ctypes.sizeof(GendrParams)))
     if L.gendr_abi_version() != ABI_VERSION:
         raise NativeLibraryError("gendr_amd: ABI version mismatch (library %d, python %d); rebuild"
                                  % (L.gendr_abi_version(), ABI_VERSION))

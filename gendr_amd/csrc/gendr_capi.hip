@@ -85,6 +85,7 @@ int check_launch()
 extern "C" {
 
 int gendr_abi_version(void) { return GENDR_ABI_VERSION; }
+int gendr_params_size(void) { return (int)sizeof(gendr_params); }
 
 const char* gendr_error_string(int code)
 {

@@ -113,6 +113,7 @@ float gendr_cull_radius(const gendr_params* p);
 
 const char* gendr_error_string(int code);
 int gendr_abi_version(void);
+int gendr_params_size(void);   /* sizeof(gendr_params) as compiled, for binding sanity checks */
 
 #ifdef __cplusplus
 }

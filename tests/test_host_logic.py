@@ -1,0 +1,108 @@
+"""Host-side behaviour of the drop-in Python surface (no GPU needed)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    for base, _dirs, files in os.walk(os.path.join(ROOT, 'gendr_amd')):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp', '.c')):
+                text = open(os.path.join(base, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle\b', text, flags=re.M), os.path.join(base, f)
+                assert 'gendr_oracle' not in text, os.path.join(base, f)
+    text = open(os.path.join(ROOT, 'include', 'gendr_hip.h')).read()
+    assert 'oracle' not in text.lower()
+
+
+def test_name_and_id_maps_match_reference_tables():
+    from gendr_amd.functional import renderer as R
+    assert R.DIST_FUNC_IDS['hard'] == R.DIST_FUNC_IDS['heaviside'] == 0
+    assert R.DIST_FUNC_IDS['hyperbolic_secant'] == R.DIST_FUNC_IDS['gudermannian'] == 7
+    assert sorted(set(R.DIST_FUNC_IDS.values())) == list(range(18))
+    assert sorted(R.AGGR_ALPHA_FUNC_IDS.values()) == list(range(10))
+    assert R.AGGR_RGB_FUNC_IDS == {'hard': 0, 'softmax': 1}
+    assert R.TEXTURE_TYPE_IDS == {'surface': 0, 'vertex': 1}
+
+
+def test_make_params_normalisation():
+    from gendr_amd.functional.renderer import make_params
+    p = make_params(128, [0.1, 0.2, 0.3], 6, np.float64(0.03), False, None, None, 300, 'yager', np.float32(2.0),
+                    'hard', 1e-3, 1e-3, 1, 100, False, 'vertex')
+    assert (p.image_size, p.dist_func, p.aggr_alpha_func, p.aggr_rgb_func, p.texture_type) == (128, 6, 6, 0, 1)
+    assert p.dist_shape == 0.0 and p.dist_shift == 0.0 and abs(p.dist_scale - 0.03) < 1e-8
+    assert abs(p.background[1] - 0.2) < 1e-7 and p.cull == 1 and p.texel_mode == 0
+    with pytest.raises(AssertionError):
+        make_params(64, [0, 0, 0], 1, -1.0, False, None, None, 1e4, 2, None, 1, 1e-3, 1e-3, 1, 100, True, 'surface')
+    with pytest.raises(AssertionError):
+        make_params(64, [0, 0, 0], 1, 1e-2, False, None, None, 0.5, 2, None, 1, 1e-3, 1e-3, 1, 100, True, 'surface')
+    with pytest.raises(KeyError):
+        make_params(64, [0, 0, 0], 'triangular', 1e-2, False, None, None, 1e4, 2, None, 1, 1e-3, 1e-3, 1, 100, True, 'surface')
+
+
+def test_gendr_module_surface():
+    import gendr_amd
+    r = gendr_amd.GenDR()
+    assert (r.image_size, r.dist_func, r.dist_scale, r.aggr_alpha_func, r.aggr_rgb_func) == (256, 'uniform', 1e-2, 'probabilistic', 'softmax')
+    assert r.double_side is False and r.texture_type == 'surface' and r.anti_aliasing is False and r.dist_eps == 1e4
+    with pytest.raises(ValueError):
+        gendr_amd.GenDR(aggr_rgb_func='median')
+    with pytest.raises(ValueError):
+        gendr_amd.GenDR(texture_type='atlas')
+    r.dist_scale = 0.5                       # options are plain attributes, read at call time
+    assert r._options()['dist_scale'] == 0.5
+    assert gendr_amd.GenDR(dist_scale=None).dist_scale is None   # opt_shape.py:139 constructs with None
+
+
+def test_cpu_tensors_are_rejected():
+    from gendr_amd.functional import render
+    fv = torch.zeros(1, 2, 3, 3)
+    tex = torch.zeros(1, 2, 1, 3)
+    with pytest.raises(TypeError):
+        render(fv, tex, image_size=16)
+
+
+def test_render_signature_matches_reference_order():
+    import inspect
+    from gendr_amd.functional import render, GenDRFunction, soft_rasterize
+    names = list(inspect.signature(render).parameters)
+    assert names == ['face_vertices', 'textures', 'image_size', 'background_color', 'dist_func', 'dist_scale',
+                     'dist_squared', 'dist_shape', 'dist_shift', 'dist_eps', 'aggr_alpha_func',
+                     'aggr_alpha_t_conorm_p', 'aggr_rgb_func', 'aggr_rgb_eps', 'aggr_rgb_gamma', 'near', 'far',
+                     'double_side', 'texture_type']
+    assert list(inspect.signature(GenDRFunction.forward).parameters)[1:] == names
+    assert inspect.signature(render).parameters['double_side'].default is True
+    assert soft_rasterize is render
+
+
+def test_geometry_helpers():
+    from gendr_amd.functional.geometry import look_at, perspective, face_vertices, get_points_from_angles, vertex_normals
+    v = torch.tensor([[[0., 0., 0.], [0.1, 0., 0.], [0., 0.1, 0.]]])
+    eye = get_points_from_angles(2.0, 0.0, 0.0)
+    assert np.allclose(eye, (0.0, 0.0, -2.0))
+    cam = look_at(v, eye)
+    assert torch.allclose(cam[0, 0], torch.tensor([0., 0., 2.]), atol=1e-6)
+    assert torch.allclose(cam[0, 1], torch.tensor([0.1, 0., 2.]), atol=1e-6)
+    p = perspective(cam, angle=45.)
+    assert torch.allclose(p[0, 1], torch.tensor([0.05, 0., 2.]), atol=1e-6)
+    f = torch.tensor([[[0, 1, 2]]])
+    assert face_vertices(v, f).shape == (1, 1, 3, 3)
+    n = vertex_normals(v, f)
+    assert torch.allclose(n[0, 0].abs(), torch.tensor([0., 0., 1.]), atol=1e-6)
+    e = get_points_from_angles(torch.tensor([2.0]), torch.tensor([30.0]), torch.tensor([-15.0]))
+    assert e.shape == (1, 3)
+
+
+def test_synthetic_scene_shape():
+    from gendr_amd.synthetic import benchmark_scene, icosphere
+    v, f = icosphere(3)
+    assert v.shape == (642, 3) and f.shape == (1280, 3)
+    fv, tex = benchmark_scene(3, subdivisions=1)
+    assert fv.shape == (3, 80, 3, 3) and tex.shape == (3, 80, 1, 3)
+    assert fv[..., :2].abs().max() < 1.0 and fv[..., 2].min() > 1.0

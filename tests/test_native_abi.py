@@ -1,0 +1,106 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/gendr_hip.h declares;
+option validation follows the reference's asserts and device-side parameter checks."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'gendr_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gendr_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported(native_lib):
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(native_lib, n), n
+
+
+def test_python_binding_lists_the_same_symbols():
+    from gendr_amd import _native
+    assert sorted(_native.EXPORTS) == _declared_functions()
+
+
+def test_struct_layout_and_version(native_lib):
+    from gendr_amd import _native
+    assert native_lib.gendr_abi_version() == _native.ABI_VERSION
+    assert native_lib.gendr_params_size() == ctypes.sizeof(_native.GendrParams)
+
+
+def _params(**kw):
+    from gendr_amd.functional.renderer import make_params
+    base = dict(image_size=64, background_color=[0, 0, 0], dist_func='uniform', dist_scale=1e-2, dist_squared=False,
+                dist_shape=None, dist_shift=None, dist_eps=1e4, aggr_alpha_func='probabilistic',
+                aggr_alpha_t_conorm_p=None, aggr_rgb_func='softmax', aggr_rgb_eps=1e-3, aggr_rgb_gamma=1e-3,
+                near=1, far=100, double_side=True, texture_type='surface')
+    base.update(kw)
+    return make_params(**base)
+
+
+@pytest.mark.parametrize("kw,code", [
+    (dict(), 0),
+    (dict(dist_func=18), -3), (dict(dist_func=-1), -3),
+    (dict(aggr_alpha_func=10), -4),
+    (dict(aggr_rgb_func=2), -5),
+    (dict(dist_func='gamma', dist_shape=-0.5), -7),
+    (dict(aggr_alpha_func='hamacher', aggr_alpha_t_conorm_p=-1.0), -8),
+    (dict(aggr_alpha_func='frank', aggr_alpha_t_conorm_p=1.0), -8),
+    (dict(aggr_alpha_func='frank'), -8),                       # None -> 0.0, invalid for frank
+    (dict(aggr_alpha_func='yager', aggr_alpha_t_conorm_p=0.0), -8),
+    (dict(aggr_alpha_func='aczel_alsina', aggr_alpha_t_conorm_p=-1.0), -8),
+    (dict(aggr_alpha_func='dombi'), -8),
+    (dict(aggr_alpha_func='schweizer_sklar', aggr_alpha_t_conorm_p=0.5), -8),
+    (dict(aggr_alpha_func='schweizer_sklar', aggr_alpha_t_conorm_p=-0.5), 0),
+    (dict(aggr_alpha_func='hamacher'), 0),                     # p = 0 is valid for hamacher (opt_shape.py:106)
+])
+def test_validate_codes(native_lib, kw, code):
+    p = _params(**kw)
+    assert native_lib.gendr_validate(ctypes.byref(p), 2, 10, 1) == code
+    assert isinstance(native_lib.gendr_error_string(code), bytes)
+
+
+def test_validate_shapes(native_lib):
+    p = _params()
+    assert native_lib.gendr_validate(ctypes.byref(p), 2, 10, 0) == -2          # T < 1
+    assert native_lib.gendr_validate(ctypes.byref(p), -1, 10, 1) == -2
+    pv = _params(texture_type='vertex')
+    assert native_lib.gendr_validate(ctypes.byref(pv), 2, 10, 3) == 0
+    assert native_lib.gendr_validate(ctypes.byref(pv), 2, 10, 4) == -6         # vertex colours need T == 3
+    assert native_lib.gendr_validate(None, 1, 1, 1) == -1
+
+
+def test_record_floats(native_lib):
+    assert native_lib.gendr_face_record_floats(0, 1) == 48
+    assert native_lib.gendr_face_record_floats(1, 3) == 52
+    assert native_lib.gendr_face_record_floats(0, 4) == 40
+
+
+def test_cull_radius_is_conservative(native_lib, oracle_mod):
+    """Beyond the reported radius the oracle's own CDF is below the skip threshold (kernel.cu:784)."""
+    import math
+    for fid in range(18):
+        for sq in (False, True):
+            p = _params(dist_func=fid, dist_scale=2e-2, dist_squared=sq, dist_shape=2.0, dist_shift=0.3)
+            r = native_lib.gendr_cull_radius(ctypes.byref(p))
+            assert r >= 0
+            if math.isinf(r) or r >= 8:
+                continue
+            for k in (1.0, 1.01, 1.5, 4.0):
+                d = r * k + 1e-7
+                x = d * d if sq else d
+                assert oracle_mod.sigmoid_forward(fid, -1.0, x, 2e-2, 2.0, 0.3) <= 1e-6, (fid, sq, r, k)
+    p = _params(dist_func='uniform')
+    p.cull = 0
+    assert math.isinf(native_lib.gendr_cull_radius(ctypes.byref(p)))
+
+
+def test_null_pointers_are_rejected_not_dereferenced(native_lib):
+    p = _params()
+    assert native_lib.gendr_forward(None, None, None, None, None, 1, 1, 1, ctypes.byref(p), None) == -1
+    assert native_lib.gendr_face_info(None, None, 1, 1, None) == -1
