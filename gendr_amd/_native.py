@@ -41,7 +41,7 @@ class GendrParams(ctypes.Structure):
 
 
 EXPORTS = (
-    "gendr_abi_version", "gendr_params_size", "gendr_error_string", "gendr_face_record_floats", "gendr_validate",
+    "gendr_abi_version", "gendr_params_size", "gendr_error_string", "gendr_workspace_bytes", "gendr_validate",
     "gendr_face_setup", "gendr_forward", "gendr_backward", "gendr_face_info",
     "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
     "gendr_cull_radius",
@@ -73,8 +73,8 @@ def lib():
     L.gendr_abi_version.argtypes = []
     L.gendr_error_string.restype = ctypes.c_char_p
     L.gendr_error_string.argtypes = [i]
-    L.gendr_face_record_floats.restype = i
-    L.gendr_face_record_floats.argtypes = [i, i]
+    L.gendr_workspace_bytes.restype = ctypes.c_ulonglong
+    L.gendr_workspace_bytes.argtypes = [i, i, i, pp]
     L.gendr_validate.restype = i
     L.gendr_validate.argtypes = [pp, i, i, i]
     L.gendr_face_setup.restype = i

@@ -56,22 +56,51 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm)
     return kGeneric[texm];
 }
 
-int fill_args(RenderArgs& a, const float* face_records, const float* textures, int B, int nf, int T, const gendr_params* p)
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Workspace {
+    size_t boxes_off, records_off, masks_off, total;
+    int tiles_x, chunks, supers_x;
+};
+
+// workspace layout: [cull boxes B*nf*4 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
+Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
+{
+    Workspace w;
+    const int texm = texture_mode(p, T);
+    w.tiles_x = (p->image_size + kTile - 1) / kTile;
+    w.chunks = (nf + 63) / 64;
+    w.supers_x = (w.tiles_x + 7) / 8;
+    w.boxes_off = 0;
+    w.records_off = align256((size_t)B * nf * 4 * sizeof(float));
+    w.masks_off = w.records_off + align256((size_t)B * nf * record_floats(texm) * sizeof(float));
+    w.total = w.masks_off + align256((size_t)B * w.tiles_x * w.tiles_x * w.chunks * sizeof(unsigned long long));
+    return w;
+}
+
+int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B, int nf, int T, const gendr_params* p)
 {
     const int texm = texture_mode(p, T);
+    const Workspace w = workspace_layout(B, nf, T, p);
     memset(&a, 0, sizeof(a));
-    a.boxes = face_records;
-    a.records = face_records + (size_t)B * nf * 4;
+    a.records = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + w.records_off);
+    a.masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + w.masks_off);
     a.textures = textures;
     a.B = B; a.nf = nf; a.T = T;
     a.R = (int)sqrt((double)T);                                  // kernel.cu:1098
     a.is = p->image_size;
-    a.tiles_x = (p->image_size + kTile - 1) / kTile;
-    a.tiles_per_image = a.tiles_x * a.tiles_x;
+    a.tiles_x = w.tiles_x;
+    a.tiles_per_image = w.tiles_x * w.tiles_x;
     a.total_tiles = a.tiles_per_image * B;
+    a.total_blocks = (a.total_tiles + (kThreads / 64) - 1) / (kThreads / 64);
+    a.chunks = w.chunks;
     a.p = *p;
     a.thr = p->dist_eps * p->dist_scale;                         // float * float, kernel.cu:725
     a.softmax_sum0 = expf(p->aggr_rgb_eps / p->aggr_rgb_gamma);  // kernel.cu:729
+    a.r_scale = 1. / (double)p->dist_scale;
+    a.r_gamma = 1. / (double)p->aggr_rgb_gamma;
+    a.r_zrange = 1. / (double)(p->far_ - p->near_);              // float subtraction first, as kernel.cu:826
+    a.r_nzrange = 1. / (double)(p->near_ - p->far_);             // kernel.cu:1026
     return texm;
 }
 
@@ -100,22 +129,22 @@ const char* gendr_error_string(int code)
     case GENDR_E_DIST_PARAM:    return "invalid distribution parameter (dist_scale < 0, dist_eps < 1, or gamma dist_shape < 0)";
     case GENDR_E_TCONORM_PARAM: return "invalid t-conorm parameter p for the chosen aggr_alpha_func";
     case GENDR_E_LAUNCH:        return "kernel launch failed";
-    case GENDR_E_WORKSPACE:     return "face_records workspace missing";
+    case GENDR_E_WORKSPACE:     return "workspace buffer missing";
     default:                    return "unknown error";
     }
 }
 
-int gendr_face_record_floats(int texture_type, int T)
+unsigned long long gendr_workspace_bytes(int B, int nf, int T, const gendr_params* p)
 {
-    const int texm = texture_type == 1 ? kTexVertex : (T == 1 ? kTexSurface1 : kTexSurfaceN);
-    return record_floats(texm) + 4;   // record + the compact cull box
+    if (!p || B < 0 || nf < 0 || T < 1 || p->image_size < 1) return 0;
+    return (unsigned long long)workspace_layout(B, nf, T, p).total;
 }
 
 int gendr_validate(const gendr_params* p, int B, int nf, int T)
 {
     if (!p) return GENDR_E_NULL;
     if (B < 0 || nf < 0 || T < 1 || p->image_size < 1 || p->image_size > 32768) return GENDR_E_SHAPE;
-    if ((long long)B * ((p->image_size + kTile - 1) / kTile) * ((p->image_size + kTile - 1) / kTile) > 0x7fffffffLL) return GENDR_E_SHAPE;
+    if ((long long)B * ((p->image_size + kTile - 1) / kTile) * ((p->image_size + kTile - 1) / kTile) > 0x3fffffffLL) return GENDR_E_SHAPE;
     if (nf >= (1 << 24)) return GENDR_E_SHAPE;                   // face index is carried in a float (kernel.cu:853,998)
     if (p->dist_func < 0 || p->dist_func >= kNumDist) return GENDR_E_DIST_FUNC;
     if (p->aggr_alpha_func < 0 || p->aggr_alpha_func >= kNumAlpha) return GENDR_E_ALPHA_FUNC;
@@ -139,12 +168,12 @@ int gendr_validate(const gendr_params* p, int B, int nf, int T)
 
 float gendr_sigmoid_forward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift)
 {
-    const DistParams d = {scale, dist_shape, dist_shift};
+    const DistParams d = make_dist_params(scale, dist_shape, dist_shift);
     return cdf_rt(function_id, sign, x, d);
 }
 float gendr_sigmoid_backward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift)
 {
-    const DistParams d = {scale, dist_shape, dist_shift};
+    const DistParams d = make_dist_params(scale, dist_shape, dist_shift);
     return pdf_rt(function_id, sign, x, d);
 }
 float gendr_t_conorm_forward(int t_conorm_id, float a_existing, float b_new, int face_id, float t_conorm_p)
@@ -168,7 +197,7 @@ float gendr_cull_radius(const gendr_params* p)
     float r_eps = sqrtf(thr) * (1.f + 1e-6f) + 1e-30f;
     if (!(r_eps == r_eps)) r_eps = INFINITY;
     if (p->dist_func == kHeaviside) return 0.f;      // outside pixels: check_pixel_inside fails, fragment = 0 (kernel.cu:762-764)
-    const DistParams d = {p->dist_scale, p->dist_shape, p->dist_shift};
+    const DistParams d = make_dist_params(p->dist_scale, p->dist_shape, p->dist_shift);
     const double limit = 0.5 * kProbThreshold;
     // x is the CDF argument: distance, or squared distance with dist_squared
     const float x_hi = p->dist_squared ? 64.f : 8.f;
@@ -200,52 +229,63 @@ int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* 
     return check_launch();
 }
 
-int gendr_face_setup(const float* faces, const float* textures, float* face_records,
+int gendr_face_setup(const float* faces, const float* textures, void* workspace,
                      int B, int nf, int T, const gendr_params* p, void* stream)
 {
     const int v = gendr_validate(p, B, nf, T);
     if (v != GENDR_OK) return v;
     const long total = (long)B * nf;
-    if (total == 0) return GENDR_OK;
+    if (total == 0 || B == 0) return GENDR_OK;
     if (!faces || !textures) return GENDR_E_NULL;
-    if (!face_records) return GENDR_E_WORKSPACE;
+    if (!workspace) return GENDR_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int texm = texture_mode(p, T);
+    const Workspace w = workspace_layout(B, nf, T, p);
+    float* boxes = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.boxes_off);
+    float* recs = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.records_off);
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + w.masks_off);
     const int blocks = (int)((total + kThreads - 1) / kThreads);
     const float sthr = sqrtf(p->dist_eps * p->dist_scale);       // sqrt(threshold), kernel.cu:725,747
     const float cull_r = gendr_cull_radius(p);
-    float* boxes = face_records;
-    float* recs = face_records + (size_t)total * 4;
     if (texm == kTexSurface1)
         hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
     else if (texm == kTexVertex)
         hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
     else
         hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
+    int e = check_launch();
+    if (e != GENDR_OK) return e;
+    // one wavefront per (image, 64x64 super-tile, 64-face chunk)
+    const long waves = (long)B * w.supers_x * w.supers_x * w.chunks;
+    const long bblocks = (waves + (kThreads / 64) - 1) / (kThreads / 64);
+    if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
+    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kThreads), 0, s, boxes, masks,
+                       B, nf, p->image_size, w.tiles_x, w.chunks, w.supers_x, p->cull);
     return check_launch();
 }
 
 int gendr_forward(const float* faces, const float* textures, float* rgba, float* aggrs_info,
-                  float* face_records, int B, int nf, int T, const gendr_params* p, void* stream)
+                  void* workspace, int B, int nf, int T, const gendr_params* p, void* stream)
 {
     const int v = gendr_validate(p, B, nf, T);
     if (v != GENDR_OK) return v;
     if (!rgba || !aggrs_info) return GENDR_E_NULL;
     if (B == 0) return GENDR_OK;
-    const int e = gendr_face_setup(faces, textures, face_records, B, nf, T, p, stream);
+    if (nf > 0 && !workspace) return GENDR_E_WORKSPACE;
+    const int e = gendr_face_setup(faces, textures, workspace, B, nf, T, p, stream);
     if (e != GENDR_OK) return e;
 
     RenderArgs a;
-    const int texm = fill_args(a, face_records, textures, B, nf, T, p);
+    const int texm = fill_args(a, workspace, textures, B, nf, T, p);
     a.rgba = rgba;
     a.aux = aggrs_info;
     const KernelEntry& k = pick_kernel(p, texm);
-    hipLaunchKernelGGL(k.fwd, dim3(a.total_tiles), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.fwd, dim3(a.total_blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
 int gendr_backward(const float* faces, const float* textures, const float* rgba, const float* aggrs_info,
-                   const float* face_records, const float* grad_rgba,
+                   const void* workspace, const float* grad_rgba,
                    float* grad_faces, float* grad_textures,
                    int B, int nf, int T, const gendr_params* p, void* stream)
 {
@@ -254,10 +294,10 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     if (v != GENDR_OK) return v;
     if (B == 0 || nf == 0) return GENDR_OK;
     if (!textures || !rgba || !aggrs_info || !grad_rgba || !grad_faces || !grad_textures) return GENDR_E_NULL;
-    if (!face_records) return GENDR_E_WORKSPACE;
+    if (!workspace) return GENDR_E_WORKSPACE;
 
     RenderArgs a;
-    const int texm = fill_args(a, face_records, textures, B, nf, T, p);
+    const int texm = fill_args(a, workspace, textures, B, nf, T, p);
     a.rgba = const_cast<float*>(rgba);
     a.aux = const_cast<float*>(aggrs_info);
     a.grad_rgba = grad_rgba;
@@ -265,7 +305,7 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.grad_textures = grad_textures;
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
-    hipLaunchKernelGGL(k.bwd, dim3(a.total_tiles), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.bwd, dim3(a.total_blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

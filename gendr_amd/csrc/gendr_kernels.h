@@ -2,24 +2,26 @@
 //
 // Replaces the three __global__ kernels of the reference
 // (gendr/cuda/generalized_renderer_cuda_kernel.cu = "kernel.cu"):
-//   forward_render_inv_cuda_kernel :620-676  ->  face_setup_kernel  (+ face_info_kernel, reference layout)
+//   forward_render_inv_cuda_kernel :620-676  ->  face_setup_kernel (+ face_info_kernel, reference layout)
+//                                                bin_faces_kernel  (new: exact tile culling)
 //   forward_render_cuda_kernel     :680-862  ->  render_forward_kernel
 //   backward_render_cuda_kernel    :866-1065 ->  render_backward_kernel
 //
-// Design (DESIGN.md has the long form):
-//   * one 256-lane workgroup = one 16x16 pixel tile of one batch item; its 4 wavefronts own
-//     the four 8x8 quadrants (lane = pixel, so the per-pixel alpha fold and online softmax keep
-//     the reference's ascending-face order without any cross-lane combination);
-//   * exact tile culling: the face-setup kernel writes, per face, a conservative box outside of
-//     which the reference itself would skip the pair (kernel.cu:747,769,784).  The workgroup
-//     ballots those boxes against its tile rectangle, compacts the surviving face indices in
-//     ascending order into LDS, stages their face records through LDS in 16-byte bursts, and
-//     each wavefront refines the list against its own 8x8 quadrant;
-//   * inside the loop every lane still applies the reference's own three skip tests, so culling
-//     only removes pairs that contribute exactly nothing;
-//   * backward recomputes the pair (as the reference does), reduces the 9 (+3 / +9) partials over
-//     the wavefront with DPP adds, accumulates per-tile sums in LDS and issues one hardware fp32
-//     atomic per (tile, face, component) instead of 12..84 per (pixel, face).
+// Design (DESIGN.md has the long form and the measurements behind it):
+//   * one wavefront = one 8x8 pixel tile, lane = pixel.  The per-pixel alpha fold and online softmax keep
+//     the reference's ascending-face order without any cross-lane combination in forward;
+//   * exact tile culling: the face-setup kernel writes, per face, a conservative box outside of which the
+//     reference itself would skip the pair (kernel.cu:747,769,784); the binning kernel ballots those boxes
+//     against every tile rectangle and leaves one bit per (tile, face) in HBM -- ascending face order for
+//     free, no atomics, shared by forward and backward;
+//   * everything a face contributes to the inner loop is wave-uniform, so it lives in SGPRs: the tile's
+//     mask words and the 176-byte face records are fetched with scalar loads (constant address space)
+//     straight out of L2 / the scalar cache.  No LDS, no barriers, 8 waves per SIMD hide the latency;
+//   * inside the loop every lane still applies the reference's own three skip tests, so culling only
+//     removes pairs that contribute exactly nothing;
+//   * backward recomputes the pair (as the reference does), reduces the 9 (+3 / +9) partials over the
+//     wavefront with DPP adds and issues one hardware fp32 atomic per (tile, face, component) instead of
+//     12..84 per (pixel, face).
 //
 // No MFMA: there is no dense contraction in this path.  Compiled with -ffp-contract=off.
 #pragma once
@@ -30,35 +32,89 @@
 #include "../../include/gendr_hip.h"
 #include "gendr_math.h"
 
+#ifndef GENDR_ABLATE
+#define GENDR_ABLATE 0   // diagnostic builds only (tools/): 1..3 cut the forward loop short after a stage
+#endif
+
 namespace gendr {
+
+// wave-uniform read-only data: loads through this pointer type with a uniform address become s_load_*
+#define GENDR_CONST_AS __attribute__((address_space(4)))
+typedef const GENDR_CONST_AS float* RecPtr;
+typedef const GENDR_CONST_AS unsigned long long* MaskPtr;
+typedef float f16v __attribute__((ext_vector_type(16), aligned(4)));
+typedef float f8v  __attribute__((ext_vector_type(8), aligned(4)));
+typedef float f4v  __attribute__((ext_vector_type(4), aligned(4)));
+
+typedef float f2v  __attribute__((ext_vector_type(2), aligned(4)));
+
+// Floats [BEGIN, END) of a face record -> dst[BEGIN..END) with the widest scalar loads that fit
+// (s_load_dwordx16 / x8 / x4 / x2): one wait per stage instead of one per field.
+template <int BEGIN, int END>
+__device__ __forceinline__ void load_record(float* dst, RecPtr r)
+{
+    if constexpr (END - BEGIN >= 16) {
+        const f16v v = *reinterpret_cast<const GENDR_CONST_AS f16v*>(r + BEGIN);
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[BEGIN + k] = v[k];
+        load_record<BEGIN + 16, END>(dst, r);
+    } else if constexpr (END - BEGIN >= 8) {
+        const f8v v = *reinterpret_cast<const GENDR_CONST_AS f8v*>(r + BEGIN);
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[BEGIN + k] = v[k];
+        load_record<BEGIN + 8, END>(dst, r);
+    } else if constexpr (END - BEGIN >= 4) {
+        const f4v v = *reinterpret_cast<const GENDR_CONST_AS f4v*>(r + BEGIN);
+#pragma unroll
+        for (int k = 0; k < 4; k++) dst[BEGIN + k] = v[k];
+        load_record<BEGIN + 4, END>(dst, r);
+    } else if constexpr (END - BEGIN >= 2) {
+        const f2v v = *reinterpret_cast<const GENDR_CONST_AS f2v*>(r + BEGIN);
+        dst[BEGIN] = v[0]; dst[BEGIN + 1] = v[1];
+        load_record<BEGIN + 2, END>(dst, r);
+    } else if constexpr (END - BEGIN == 1) {
+        dst[BEGIN] = r[BEGIN];
+    }
+}
+
+// double stored in two consecutive floats of the face record (see div_by() in gendr_math.h)
+__device__ __forceinline__ double rec_double(const float* r, int k)
+{
+    return __hiloint2double(__float_as_int(r[k + 1]), __float_as_int(r[k]));
+}
 
 // ---------------------------------------------------------------------------------------------
 // face record layout (floats).  Geometry part is common; the tail depends on the texture mode.
 // ---------------------------------------------------------------------------------------------
+// Ordered by the stage of the inner loop that consumes it, so that each stage is one contiguous scalar load:
+//   stage 1 [0,16)   box + barycentric matrix + flags          -> per-lane box test, barycentrics
+//   stage 2 [16,38)  edge data + vertex x,y                     -> point-to-triangle distance
+//   stage 3 [38,REC) reciprocal vertex depths + texels          -> depth, colour
+// Divisors that are uniform over the wavefront are stored as correctly rounded DOUBLE reciprocals
+// (see div_by()).
 constexpr int kRecBox   = 0;    // xlo, xhi, ylo, yhi : pixel centres outside are skipped
 constexpr int kRecInv   = 4;    // inv[9]   (kernel.cu:645-657)
-constexpr int kRecEdge  = 13;   // A[3][3]  A[k][j] = sym[k][j] - sym[(k+1)%3][j]  (kernel.cu:95-97,146-148)
-constexpr int kRecDen   = 22;   // Dn[3]    Dn[k] = A[k][k] - A[k][(k+1)%3]        (denominator of :99,:150)
-constexpr int kRecVert  = 25;   // the 9 input floats x0 y0 z0 x1 y1 z1 x2 y2 z2
-constexpr int kRecBits  = 34;   // int bits: 1,2,4 = first obtuse corner 0,1,2 (:667-675); 8 = front side (:56-58)
-constexpr int kRecSpare = 35;
-constexpr int kRecTex   = 36;   // TEXM 0: own rgb, next-face rgb ; TEXM 1: 3 vertex colours ; TEXM 2: nothing
+constexpr int kRecBits  = 13;   // int bits: 1,2,4 = first obtuse corner 0,1,2 (:667-675); 8 = front side (:56-58)
+constexpr int kRecEdge  = 16;   // A[3][3]  A[k][j] = sym[k][j] - sym[(k+1)%3][j]  (kernel.cu:95-97,146-148)
+constexpr int kRecRDen  = 26;   // 3 doubles: 1 / Dn[k],  Dn[k] = A[k][k] - A[k][(k+1)%3]  (denominator of :99,:150)
+constexpr int kRecXY    = 32;   // x0 y0 x1 y1 x2 y2
+constexpr int kRecRZ    = 38;   // 3 doubles: 1 / z_k   (:809, :1027-1029)
+constexpr int kRecTex   = 44;   // TEXM 0: own rgb, next-face rgb ; TEXM 1: 3 vertex colours ; TEXM 2: nothing
+constexpr int kRecStage2 = 16, kRecStage3 = 38;
 
 // texture modes of the kernels
 constexpr int kTexSurface1 = 0;   // texture_type surface, T == 1 (default Mesh texture): texels staged in the record
 constexpr int kTexVertex   = 1;   // texture_type vertex (T == 3): 9 floats staged in the record
 constexpr int kTexSurfaceN = 2;   // texture_type surface, T = R*R > 1: texels read from HBM/L2 per pair
 
-__host__ __device__ constexpr int record_floats(int texm) { return texm == kTexSurface1 ? 44 : (texm == kTexVertex ? 48 : 36); }
+__host__ __device__ constexpr int record_floats(int texm) { return texm == kTexSurface1 ? 52 : (texm == kTexVertex ? 56 : 44); }
 
-constexpr int kTile      = 16;    // tile edge in pixels
-constexpr int kThreads   = 256;
-constexpr int kListCap   = 4096;  // face indices per scan range (uint16 in LDS)
-constexpr int kRecCap    = 160;   // face records resident in LDS at a time
+constexpr int kTile    = 8;     // one wavefront renders an 8x8 pixel tile
+constexpr int kThreads = 256;   // 4 independent wave-tiles per workgroup
 
 struct RenderArgs {
-    const float*  boxes;        // [B*nf][4]
     const float*  records;      // [B*nf][REC]
+    const unsigned long long* masks;   // [B*tiles][chunks] : bit f of chunk c set = face 64c+f may touch the tile
     const float*  textures;     // [B,nf,T,3]
     float*        rgba;         // [B,4,is,is]
     float*        aux;          // [B,2,is,is]
@@ -66,11 +122,15 @@ struct RenderArgs {
     float*        grad_faces;   // backward only
     float*        grad_textures;
     int B, nf, T, R, is;
-    int tiles_x, tiles_per_image, total_tiles;
+    int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
     gendr_params p;
     float thr;                  // dist_eps * dist_scale (kernel.cu:725)
     float softmax_sum0;         // exp(aggr_rgb_eps / aggr_rgb_gamma) (kernel.cu:729)
-    float inv_unused;
+    // correctly rounded double reciprocals of the per-call divisors (see div_by)
+    double r_scale;             // 1 / dist_scale
+    double r_gamma;             // 1 / aggr_rgb_gamma
+    double r_zrange;            // 1 / (far - near)        (kernel.cu:826)
+    double r_nzrange;           // 1 / (near - far)        (kernel.cu:1026)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -187,18 +247,21 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     r[kRecBox + 0] = xlo; r[kRecBox + 1] = xhi; r[kRecBox + 2] = ylo; r[kRecBox + 3] = yhi;
 #pragma unroll
     for (int k = 0; k < 9; k++) r[kRecInv + k] = g.inv[k];
+    r[kRecBits] = __int_as_float(g.obt | (g.front << 3));
+    r[14] = 0.f; r[15] = 0.f;
+    double* rden = reinterpret_cast<double*>(r + kRecRDen);
+    double* rz = reinterpret_cast<double*>(r + kRecRZ);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int k1 = (k + 1) % 3;
         float a[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) { a[j] = g.sym[3 * k + j] - g.sym[3 * k1 + j]; r[kRecEdge + 3 * k + j] = a[j]; }
-        r[kRecDen + k] = a[k] - a[k1];
+        rden[k] = 1. / (double)(a[k] - a[k1]);
+        r[kRecXY + 2 * k] = f[3 * k]; r[kRecXY + 2 * k + 1] = f[3 * k + 1];
+        rz[k] = 1. / (double)f[3 * k + 2];
     }
-#pragma unroll
-    for (int k = 0; k < 9; k++) r[kRecVert + k] = f[k];
-    r[kRecBits] = __int_as_float(g.obt | (g.front << 3));
-    r[kRecSpare] = 0.f;
+    r[25] = 0.f;
     if (TEXM == kTexSurface1) {
         const long nxt = (i + 1 < total_faces) ? i + 1 : i;   // reference reads the next face's texel (:179-182); none after the last
 #pragma unroll
@@ -231,60 +294,22 @@ __global__ __launch_bounds__(kThreads) void face_info_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile bookkeeping shared by forward and backward
+// pixel / tile geometry
 // ---------------------------------------------------------------------------------------------
-struct TileCtx {
-    int   b;            // batch item
-    int   tx0, ty0;     // first pixel column / image row of the tile
-    int   xi, row;      // this lane's pixel
-    bool  valid;        // pixel inside the image
-    float xp, yp;       // pixel centre, kernel.cu:716-719
-    long  pix;          // row * is + xi
-    // wave quadrant rectangle in pixel-centre coordinates (inclusive)
-    float qx_lo, qx_hi, qy_lo, qy_hi;
-    // whole-tile rectangle
-    float tx_lo, tx_hi, ty_lo, ty_hi;
-};
-
+// (2.*idx + 1. - is) / is of kernel.cu:718-719.  The reference evaluates it in double and rounds to float;
+// numerator and denominator are integers below 2^24, so the float division rounds to the same value.
 __device__ __forceinline__ float pixel_coord(int idx, int is)
 {
-    return (float)((2. * idx + 1. - is) / is);   // (2.*xi + 1. - is) / is, kernel.cu:718-719
+    return (float)(2 * idx + 1 - is) / (float)is;
 }
 
-// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8).  Remap so that each XCD
-// walks a contiguous range of tiles: all 256 tiles of one image then hit the same 4 MiB L2 for that
-// image's face records.  Affects speed only.
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8).  Remap so that each XCD walks a
+// contiguous range of tiles: all tiles of one image then hit the same 4 MiB L2 for that image's face
+// records and masks.  Affects speed only.
 __device__ __forceinline__ int xcd_remap(int b, int n)
 {
     const int xcd = b & 7, idx = b >> 3, per = n >> 3, rem = n & 7;
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
-}
-
-__device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a)
-{
-    const int tile = xcd_remap(blockIdx.x, a.total_tiles);
-    t.b = tile / a.tiles_per_image;
-    const int tl = tile - t.b * a.tiles_per_image;
-    const int tyi = tl / a.tiles_x, txi = tl - tyi * a.tiles_x;
-    t.tx0 = txi * kTile;
-    t.ty0 = tyi * kTile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qx0 = t.tx0 + (wave & 1) * 8, qy0 = t.ty0 + (wave >> 1) * 8;
-    t.xi = qx0 + (lane & 7);
-    t.row = qy0 + (lane >> 3);
-    t.valid = t.xi < a.is && t.row < a.is;
-    const int is = a.is;
-    t.xp = pixel_coord(t.xi, is);
-    t.yp = pixel_coord(is - 1 - t.row, is);   // yi = is - 1 - row, kernel.cu:716
-    t.pix = (long)t.row * is + t.xi;
-    t.qx_lo = pixel_coord(qx0, is);
-    t.qx_hi = pixel_coord(min(qx0 + 7, is - 1), is);
-    t.qy_hi = pixel_coord(is - 1 - qy0, is);
-    t.qy_lo = pixel_coord(is - 1 - min(qy0 + 7, is - 1), is);
-    t.tx_lo = pixel_coord(t.tx0, is);
-    t.tx_hi = pixel_coord(min(t.tx0 + kTile - 1, is - 1), is);
-    t.ty_hi = pixel_coord(is - 1 - t.ty0, is);
-    t.ty_lo = pixel_coord(is - 1 - min(t.ty0 + kTile - 1, is - 1), is);
 }
 
 // box = (xlo, xhi, ylo, yhi).  A rectangle of pixel centres misses the box iff every centre fails the
@@ -294,120 +319,129 @@ __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry
     return !(rx_lo > box.y || rx_hi < box.x || ry_lo > box.w || ry_hi < box.z);
 }
 
-struct TileLds {
-    uint16_t list[kListCap];        // face indices relative to the scan range, ascending
-    uint16_t wlist[4][kRecCap];     // per-wave record slots, ascending
-    int      wave_tot[2][4];
+// ---------------------------------------------------------------------------------------------
+// binning: masks[b][tile][chunk], bit f of chunk c = face 64c+f of image b may touch the 8x8 tile.
+// One wavefront takes 64 faces (lane = face, coalesced box load) and a block of 8x8 tiles (a 64x64 pixel
+// super-tile): for every tile of the block the ballot of "box meets tile" IS the mask word; lane t keeps the
+// word of tile t and the 64 words leave in one store.  A chunk whose union box misses the super-tile writes
+// zeros without looping.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bin_faces_kernel(
+    const float* __restrict__ boxes, unsigned long long* __restrict__ masks,
+    int B, int nf, int is, int tiles_x, int chunks, int supers_x, int cull)
+{
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const long per_image = (long)supers_x * supers_x * chunks;
+    if (wid >= per_image * B) return;
+    const int b = (int)(wid / per_image);
+    long rem = wid - (long)b * per_image;
+    const int sup = (int)(rem / chunks), c = (int)(rem - (long)sup * chunks);
+    const int sy = sup / supers_x, sx = sup - sy * supers_x;
+
+    const int fi = c * 64 + lane;
+    const bool have = fi < nf;
+    float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
+    if (have) box = reinterpret_cast<const float4*>(boxes)[(long)b * nf + fi];
+
+    // lane t owns tile t of the super-tile: its rectangle (computed once) and, at the end, its mask word
+    const int ty_l = sy * 8 + (lane >> 3), tx_l = sx * 8 + (lane & 7);
+    const bool tile_ok = ty_l < tiles_x && tx_l < tiles_x;
+    const float rx_lo_l = pixel_coord(tx_l * 8, is), rx_hi_l = pixel_coord(min(tx_l * 8 + 7, is - 1), is);
+    const float ry_hi_l = pixel_coord(is - 1 - ty_l * 8, is), ry_lo_l = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is);
+    unsigned long long mine = 0ull;
+
+    // union of the chunk's boxes against the super-tile rectangle
+    const float sx_lo = pixel_coord(sx * 64, is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is);
+    const float sy_hi = pixel_coord(is - 1 - sy * 64, is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is);
+    const bool any_hit = cull ? __any(have && rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box)) : true;
+    if (any_hit) {
+        const unsigned long long ok_tiles = __ballot(tile_ok);
+        for (int t = 0; t < 64; t++) {
+            if (!((ok_tiles >> t) & 1ull)) continue;                         // uniform
+            const float rx_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_lo_l), t));
+            const float rx_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_hi_l), t));
+            const float ry_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_lo_l), t));
+            const float ry_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_hi_l), t));
+            const bool hit = have && (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, box) : true);
+            const unsigned long long m = __ballot(hit);
+            if (lane == t) mine = m;
+        }
+    }
+    if (tile_ok)
+        masks[((long)b * tiles_x * tiles_x + (long)ty_l * tiles_x + tx_l) * chunks + c] = mine;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-tile bookkeeping shared by forward and backward
+// ---------------------------------------------------------------------------------------------
+struct TileCtx {
+    int   b;            // batch item
+    int   tile;         // global tile id (b * tiles_per_image + ty * tiles_x + tx)
+    int   xi, row;      // this lane's pixel
+    bool  valid;        // pixel inside the image
+    float xp, yp;       // pixel centre, kernel.cu:716-719
+    long  pix;          // row * is + xi
 };
 
-// Scans faces [range0, range1) of batch item t.b; leaves the ascending list of faces whose box meets the
-// tile rectangle in lds.list and returns its length (identical in every thread).
-__device__ __forceinline__ int scan_faces(const RenderArgs& a, const TileCtx& t, TileLds& lds, int range0, int range1)
+__device__ __forceinline__ bool tile_setup(TileCtx& t, const RenderArgs& a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float4* boxes = reinterpret_cast<const float4*>(a.boxes) + (long)t.b * a.nf;
-    int count = 0, parity = 0;
-    for (int base = range0; base < range1; base += kThreads) {
-        const int fi = base + threadIdx.x;
-        bool hit = false;
-        if (fi < range1) {
-            const float4 box = boxes[fi];
-            hit = a.p.cull ? rect_hits_box(t.tx_lo, t.tx_hi, t.ty_lo, t.ty_hi, box) : true;
-        }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) lds.wave_tot[parity][wave] = __popcll(m);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const int c = lds.wave_tot[parity][w];
-            before += (w < wave) ? c : 0;
-            total += c;
-        }
-        if (hit) {
-            const int pos = count + before + __popcll(m & ((1ull << lane) - 1ull));
-            lds.list[pos] = (uint16_t)(fi - range0);
-        }
-        count += total;
-        parity ^= 1;
-    }
-    __syncthreads();
-    return count;
-}
-
-// Copies records of list[c0 .. c0+n) into LDS, 16 bytes per lane per step.
-template <int REC>
-__device__ __forceinline__ void stage_records(const RenderArgs& a, const TileCtx& t, const TileLds& lds,
-                                              float* s_rec, int range0, int c0, int n)
-{
-    constexpr int Q = REC / 4;   // float4 per record
-    const float4* src = reinterpret_cast<const float4*>(a.records);
-    float4* dst = reinterpret_cast<float4*>(s_rec);
-    for (int e = threadIdx.x; e < n * Q; e += kThreads) {
-        const int slot = e / Q, q = e - slot * Q;
-        const long face = (long)t.b * a.nf + range0 + lds.list[c0 + slot];
-        dst[slot * Q + q] = src[face * Q + q];
-    }
-}
-
-// Each wave keeps the slots whose box meets its own 8x8 quadrant (ascending).  Returns the count.
-template <int REC>
-__device__ __forceinline__ int wave_refine(const RenderArgs& a, const TileCtx& t, TileLds& lds, const float* s_rec, int n)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int wn = 0;
-    for (int s0 = 0; s0 < n; s0 += 64) {
-        const int s = s0 + lane;
-        bool hit = false;
-        if (s < n) {
-            const float4 box = *reinterpret_cast<const float4*>(s_rec + s * REC + kRecBox);
-            hit = a.p.cull ? rect_hits_box(t.qx_lo, t.qx_hi, t.qy_lo, t.qy_hi, box) : true;
-        }
-        const unsigned long long m = __ballot(hit);
-        if (hit) lds.wlist[wave][wn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
-        wn += __popcll(m);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return wn;
+    // 4 consecutive tiles of an image row per workgroup; uniform per wave
+    const int tile = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, a.total_blocks) * (kThreads / 64) + wave);
+    if (tile >= a.total_tiles) return false;
+    t.tile = tile;
+    t.b = tile / a.tiles_per_image;
+    const int tl = tile - t.b * a.tiles_per_image;
+    const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
+    t.xi = tx * kTile + (lane & 7);
+    t.row = ty * kTile + (lane >> 3);
+    t.valid = t.xi < a.is && t.row < a.is;
+    t.xp = pixel_coord(t.xi, a.is);
+    t.yp = pixel_coord(a.is - 1 - t.row, a.is);   // yi = is - 1 - row, kernel.cu:716
+    t.pix = (long)t.row * a.is + t.xi;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
 // one (pixel, face) evaluation: kernel.cu:747-786 (forward) == :924-962 (backward)
 // ---------------------------------------------------------------------------------------------
 struct Pair {
-    float w[3];        // barycentrics (:39-43)
-    float t[3];        // t - w of the closest boundary point (:103-105,:157)
+    float w0, w1, w2;        // barycentrics (:39-43)
+    float t0, t1, t2;        // t - w of the closest boundary point (:103-105,:157)
     float sign, dx, dy, dis, frag;
 };
 
 __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 
-// kernel.cu:76-165 on the staged record.  Returns false when the pair must be dropped (NaN barycentrics:
+// kernel.cu:76-165 on the face record.  Returns false when the pair must be dropped (NaN barycentrics:
 // the reference indexes with v0 = -1 there; DESIGN.md quirk iv).
-__device__ __forceinline__ bool point_to_face(Pair& q, const float* __restrict__ r, float xp, float yp)
+__device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp, float yp)
 {
-    const float w0 = q.w[0], w1 = q.w[1], w2 = q.w[2];
-    const float x0 = r[kRecVert + 0], y0 = r[kRecVert + 1], x1 = r[kRecVert + 3], y1 = r[kRecVert + 4],
-                x2 = r[kRecVert + 6], y2 = r[kRecVert + 7];
+    const float w0 = q.w0, w1 = q.w1, w2 = q.w2;
+    const float x0 = r[kRecXY + 0], y0 = r[kRecXY + 1], x1 = r[kRecXY + 2], y1 = r[kRecXY + 3],
+                x2 = r[kRecXY + 4], y2 = r[kRecXY + 5];
     if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
-        float best = 100000000.f, bx = 0.f, by = 0.f, bt0 = 0.f, bt1 = 0.f, bt2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int k1 = (k + 1) % 3;
-            const float* A = r + kRecEdge + 3 * k;
-            const float tv = (w0 * A[0] + w1 * A[1] + w2 * A[2] - A[k1]) / r[kRecDen + k];
-            float t0[3];
-            t0[k] = tv;
-            t0[k1] = 1 - tv;
-            t0[(k + 2) % 3] = 0;
-            t0[0] -= w0; t0[1] -= w1; t0[2] -= w2;
-            const float ddx = t0[0] * x0 + t0[1] * x1 + t0[2] * x2;
-            const float ddy = t0[0] * y0 + t0[1] * y1 + t0[2] * y2;
-            const float d = ddx * ddx + ddy * ddy;
-            if (d < best) { best = d; bx = ddx; by = ddy; bt0 = t0[0]; bt1 = t0[1]; bt2 = t0[2]; }
-        }
-        q.dx = bx; q.dy = by; q.sign = 1.f;
-        q.t[0] = bt0; q.t[1] = bt1; q.t[2] = bt2;
+        // edge k joins vertex k and k+1: t0[k] = tv, t0[k+1] = 1 - tv, t0[k+2] = 0, then t0 -= w (:91-105)
+        const float tva = div_by((w0 * r[kRecEdge + 0] + w1 * r[kRecEdge + 1] + w2 * r[kRecEdge + 2] - r[kRecEdge + 1]), rec_double(r, kRecRDen + 0));
+        const float a0 = tva - w0, a1 = (1 - tva) - w1, a2 = 0.f - w2;
+        const float adx = a0 * x0 + a1 * x1 + a2 * x2, ady = a0 * y0 + a1 * y1 + a2 * y2;
+        const float ad = adx * adx + ady * ady;
+        const float tvb = div_by((w0 * r[kRecEdge + 3] + w1 * r[kRecEdge + 4] + w2 * r[kRecEdge + 5] - r[kRecEdge + 5]), rec_double(r, kRecRDen + 2));
+        const float b0 = 0.f - w0, b1 = tvb - w1, b2 = (1 - tvb) - w2;
+        const float bdx = b0 * x0 + b1 * x1 + b2 * x2, bdy = b0 * y0 + b1 * y1 + b2 * y2;
+        const float bd = bdx * bdx + bdy * bdy;
+        const float tvc = div_by((w0 * r[kRecEdge + 6] + w1 * r[kRecEdge + 7] + w2 * r[kRecEdge + 8] - r[kRecEdge + 6]), rec_double(r, kRecRDen + 4));
+        const float c0 = (1 - tvc) - w0, c1 = 0.f - w1, c2 = tvc - w2;
+        const float cdx = c0 * x0 + c1 * x1 + c2 * x2, cdy = c0 * y0 + c1 * y1 + c2 * y2;
+        const float cd = cdx * cdx + cdy * cdy;
+        // running strict minimum in edge order 0,1,2 starting from 1e8 (:86,:112)
+        float best = 100000000.f;
+        q.dx = 0.f; q.dy = 0.f; q.t0 = 0.f; q.t1 = 0.f; q.t2 = 0.f;
+        if (ad < best) { best = ad; q.dx = adx; q.dy = ady; q.t0 = a0; q.t1 = a1; q.t2 = a2; }
+        if (bd < best) { best = bd; q.dx = bdx; q.dy = bdy; q.t0 = b0; q.t1 = b1; q.t2 = b2; }
+        if (cd < best) { best = cd; q.dx = cdx; q.dy = cdy; q.t0 = c0; q.t1 = c1; q.t2 = c2; }
+        q.sign = 1.f;
         return true;
     }
     const int bits = __float_as_int(r[kRecBits]);
@@ -429,47 +463,59 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* __restrict__
         int m = 0; float wm = w0;
         if (w1 < wm) { m = 1; wm = w1; }
         if (w2 < wm) { m = 2; }
-        v0 = (m + 1) % 3;
+        v0 = m == 2 ? 0 : m + 1;
     }
-    const int v1 = v0 == 2 ? 0 : v0 + 1;
-    const float A0 = sel3(v0, r[kRecEdge + 0], r[kRecEdge + 3], r[kRecEdge + 6]);
-    const float A1 = sel3(v0, r[kRecEdge + 1], r[kRecEdge + 4], r[kRecEdge + 7]);
-    const float A2 = sel3(v0, r[kRecEdge + 2], r[kRecEdge + 5], r[kRecEdge + 8]);
-    const float Av1 = sel3(v1, A0, A1, A2);
-    const float den = sel3(v0, r[kRecDen + 0], r[kRecDen + 1], r[kRecDen + 2]);
-    const float tv = (w0 * A0 + w1 * A1 + w2 * A2 - Av1) / den;
-    const float tv0 = fminf(fmaxf(tv, 0.f), 1.f);          // min(max(t, 0.), 1.) : clamp is exact in either precision
-    const float tv1 = fminf(fmaxf(1 - tv, 0.f), 1.f);
-    // t[v0] = tv0, t[v1] = tv1, t[v2] = clamp(0) = 0 ; then t[k] -= w[k]
-    const float t0 = (v0 == 0 ? tv0 : (v1 == 0 ? tv1 : 0.f)) - w0;
-    const float t1 = (v0 == 1 ? tv0 : (v1 == 1 ? tv1 : 0.f)) - w1;
-    const float t2 = (v0 == 2 ? tv0 : (v1 == 2 ? tv1 : 0.f)) - w2;
-    q.t[0] = t0; q.t[1] = t1; q.t[2] = t2;
-    q.dx = t0 * x0 + t1 * x1 + t2 * x2;
-    q.dy = t0 * y0 + t1 * y1 + t2 * y2;
+    const bool e0 = v0 == 0, e1 = v0 == 1;       // selected edge: v0 -> v0+1
+    // read every candidate into a value first: selecting between array elements directly lets the compiler
+    // turn the select into a dynamically indexed load, which would push the record out of SGPRs
+    const float E00 = r[kRecEdge + 0], E01 = r[kRecEdge + 1], E02 = r[kRecEdge + 2];
+    const float E10 = r[kRecEdge + 3], E11 = r[kRecEdge + 4], E12 = r[kRecEdge + 5];
+    const float E20 = r[kRecEdge + 6], E21 = r[kRecEdge + 7], E22 = r[kRecEdge + 8];
+    const double D0 = rec_double(r, kRecRDen + 0), D1 = rec_double(r, kRecRDen + 2), D2 = rec_double(r, kRecRDen + 4);
+    const float A0 = e0 ? E00 : (e1 ? E10 : E20);
+    const float A1 = e0 ? E01 : (e1 ? E11 : E21);
+    const float A2 = e0 ? E02 : (e1 ? E12 : E22);
+    const float Av1 = e0 ? A1 : (e1 ? A2 : A0);   // a0[v1]
+    const double rden = e0 ? D0 : (e1 ? D1 : D2);
+    const float tv = div_by(w0 * A0 + w1 * A1 + w2 * A2 - Av1, rden);
+    const float ta = fminf(fmaxf(tv, 0.f), 1.f);           // min(max(t, 0.), 1.) : the clamp is exact in either precision
+    const float tb = fminf(fmaxf(1 - tv, 0.f), 1.f);
+    // t[v0] = ta, t[v0+1] = tb, t[v0+2] = clamp(0) = 0 ; then t[k] -= w[k]  (:150-158)
+    q.t0 = (e0 ? ta : (e1 ? 0.f : tb)) - w0;
+    q.t1 = (e0 ? tb : (e1 ? ta : 0.f)) - w1;
+    q.t2 = (e0 ? 0.f : (e1 ? tb : ta)) - w2;
+    q.dx = q.t0 * x0 + q.t1 * x1 + q.t2 * x2;
+    q.dy = q.t0 * y0 + q.t1 * y1 + q.t2 * y2;
     q.sign = -1.f;
     return true;
 }
 
-__device__ __forceinline__ bool inside_closed(const float* w)
+__device__ __forceinline__ bool inside_closed(const Pair& q)
 {
-    return w[0] <= 1 && w[0] >= 0 && w[1] <= 1 && w[1] >= 0 && w[2] <= 1 && w[2] >= 0;   // :62-64
+    return q.w0 <= 1 && q.w0 >= 0 && q.w1 <= 1 && q.w1 >= 0 && q.w2 <= 1 && q.w2 >= 0;   // :62-64
 }
 
-// Returns true if the pair contributes (none of the skips at :747, :769, :784 fires).
-template <int DIST, int SQ>
-__device__ __forceinline__ bool eval_pair(Pair& q, const float* __restrict__ r, float xp, float yp,
-                                          const RenderArgs& a, const DistParams& dp)
+// stage 1: the reference's border test (:747) tightened to the exact cull box, on r[0..16)
+__device__ __forceinline__ bool inside_box(const float* r, float xp, float yp)
 {
-    const float4 box = *reinterpret_cast<const float4*>(r + kRecBox);
-    if (xp > box.y || xp < box.x || yp > box.w || yp < box.z) return false;
-    q.w[0] = r[kRecInv + 0] * xp + r[kRecInv + 1] * yp + r[kRecInv + 2];
-    q.w[1] = r[kRecInv + 3] * xp + r[kRecInv + 4] * yp + r[kRecInv + 5];
-    q.w[2] = r[kRecInv + 6] * xp + r[kRecInv + 7] * yp + r[kRecInv + 8];
+    return !(xp > r[kRecBox + 1] || xp < r[kRecBox + 0] || yp > r[kRecBox + 3] || yp < r[kRecBox + 2]);
+}
+__device__ __forceinline__ void barycentrics(Pair& q, const float* r, float xp, float yp)   // :39-43
+{
+    q.w0 = r[kRecInv + 0] * xp + r[kRecInv + 1] * yp + r[kRecInv + 2];
+    q.w1 = r[kRecInv + 3] * xp + r[kRecInv + 4] * yp + r[kRecInv + 5];
+    q.w2 = r[kRecInv + 6] * xp + r[kRecInv + 7] * yp + r[kRecInv + 8];
+}
+
+// stage 2 on r[16..34): soft fragment of a pair whose pixel is inside the box.  Returns true if the pair
+// contributes (none of the skips at :769, :784 fires).
+template <int DIST, int SQ>
+__device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp, float yp, const RenderArgs& a, const DistParams& dp)
+{
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     if (dist == kHeaviside) {
-        q.sign = 0.f; q.dx = 0.f; q.dy = 0.f; q.dis = 0.f; q.t[0] = q.t[1] = q.t[2] = 0.f;
-        q.frag = inside_closed(q.w) ? 1.f : 0.f;                                    // :762-764
+        q.sign = 0.f; q.dx = 0.f; q.dy = 0.f; q.dis = 0.f; q.t0 = q.t1 = q.t2 = 0.f;
+        q.frag = inside_closed(q) ? 1.f : 0.f;                                      // :762-764
     } else {
         if (!point_to_face(q, r, xp, yp)) return false;
         float dis = q.dx * q.dx + q.dy * q.dy;                                      // :768
@@ -484,15 +530,15 @@ __device__ __forceinline__ bool eval_pair(Pair& q, const float* __restrict__ r, 
 }
 
 // barycentric_clip + depth, kernel.cu:68-72, :807-810
-__device__ __forceinline__ float clip_and_depth(const Pair& q, const float* __restrict__ r, float* wc)
+__device__ __forceinline__ float clip_and_depth(const Pair& q, const float* r, float* wc)
 {
-#pragma unroll
-    for (int k = 0; k < 3; k++) wc[k] = fmaxf(fminf(q.w[k], 1.f), 0.f);
+    wc[0] = fmaxf(fminf(q.w0, 1.f), 0.f);
+    wc[1] = fmaxf(fminf(q.w1, 1.f), 0.f);
+    wc[2] = fmaxf(fminf(q.w2, 1.f), 0.f);
     float s = wc[0] + wc[1] + wc[2];
     s = ((double)s > 1e-5) ? s : (float)1e-5;              // max(sum, 1e-5) with a double literal, stored as float
-#pragma unroll
-    for (int k = 0; k < 3; k++) wc[k] /= s;
-    return 1.f / (wc[0] / r[kRecVert + 2] + wc[1] / r[kRecVert + 5] + wc[2] / r[kRecVert + 8]);   // "1. /": one rounding
+    wc[0] /= s; wc[1] /= s; wc[2] /= s;
+    return 1.f / (div_by(wc[0], rec_double(r, kRecRZ + 0)) + div_by(wc[1], rec_double(r, kRecRZ + 2)) + div_by(wc[2], rec_double(r, kRecRZ + 4)));   // "1. /": one rounding
 }
 
 // surface texel index for clipped barycentrics (kernel.cu:179-185); may be >= T (reference quirk)
@@ -529,8 +575,7 @@ __device__ __forceinline__ long resolve_texel(const float* wc, const RenderArgs&
 
 // colour sampled for a pair.  TEXM 0: own or next-face texel out of the record.
 template <int TEXM>
-__device__ __forceinline__ void sample_colour(float* c, int& own, const float* wc, const float* __restrict__ r,
-                                              const RenderArgs& a, long face_lin)
+__device__ __forceinline__ void sample_colour(float* c, int& own, const float* wc, const float* r, const RenderArgs& a, long face_lin)
 {
     if (TEXM == kTexSurface1) {
         int idx = texel_index(wc, 1, a.p.texel_mode == 1);
@@ -539,13 +584,17 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
         if (a.p.texel_mode == 1) { idx = 0; own = 0; }
         if (idx != 0 && last) idx = 0;                      // nothing after the last face: own texel, still no gradient
         // idx is 0 (own) or 1 (next face) for R == 1; a negative index cannot occur here
-        const float* tx = r + kRecTex + (idx != 0 ? 3 : 0);
-        c[0] = tx[0]; c[1] = tx[1]; c[2] = tx[2];
+        const bool nxt = idx != 0;
+        const float o0 = r[kRecTex + 0], o1 = r[kRecTex + 1], o2 = r[kRecTex + 2];
+        const float n0 = r[kRecTex + 3], n1 = r[kRecTex + 4], n2 = r[kRecTex + 5];
+        c[0] = nxt ? n0 : o0;
+        c[1] = nxt ? n1 : o1;
+        c[2] = nxt ? n2 : o2;
     } else if (TEXM == kTexVertex) {
         own = 0;
-        const float* tx = r + kRecTex;
 #pragma unroll
-        for (int k = 0; k < 3; k++) c[k] = wc[0] * tx[k] + wc[1] * tx[3 + k] + wc[2] * tx[6 + k];   // :187-189
+        for (int k = 0; k < 3; k++)
+            c[k] = wc[0] * r[kRecTex + k] + wc[1] * r[kRecTex + 3 + k] + wc[2] * r[kRecTex + 6 + k];   // :187-189
     } else {
         const long at = resolve_texel(wc, a, face_lin, own);
 #pragma unroll
@@ -560,14 +609,10 @@ template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderArgs a)
 {
     constexpr int REC = record_floats(TEXM);
-    __shared__ __attribute__((aligned(16))) float s_rec[kRecCap * REC];
-    __shared__ TileLds lds;
-
     TileCtx t;
-    tile_setup(t, a);
-    const int wave = threadIdx.x >> 6;
+    if (!tile_setup(t, a)) return;
     const long P = (long)a.is * a.is;
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift};
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     const float gam = a.p.aggr_rgb_gamma;
@@ -585,63 +630,75 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
     float depth_min = 10000000.f;
     int face_min = -1;
 
-    for (int range0 = 0; range0 < a.nf; range0 += kListCap) {
-        const int range1 = min(a.nf, range0 + kListCap);
-        const int count = scan_faces(a, t, lds, range0, range1);
-        for (int c0 = 0; c0 < count; c0 += kRecCap) {
-            const int n = min(kRecCap, count - c0);
-            if (c0 > 0) __syncthreads();                 // previous chunk fully consumed
-            stage_records<REC>(a, t, lds, s_rec, range0, c0, n);
-            __syncthreads();
-            const int wn = wave_refine<REC>(a, t, lds, s_rec, n);
+    const MaskPtr mrow = (MaskPtr)a.masks + (long)t.tile * a.chunks;
+    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
+    for (int c = 0; c < a.chunks; c++) {
+        unsigned long long w = mrow[c];
+        while (w) {
+            const int fn = c * 64 + __builtin_ctzll(w);
+            w &= w - 1;
+            const RecPtr rp = recs + (long)fn * REC;
+            float r[REC];
+            load_record<0, 16>(r, rp);
+            bool live = t.valid && inside_box(r, t.xp, t.yp);
+            if (!__any(live)) continue;                      // whole wave outside the box: no further loads
+#if GENDR_ABLATE == 1
+            if (live) alpha += r[kRecInv];
+            continue;
+#endif
+            Pair q;
+            barycentrics(q, r, t.xp, t.yp);
+            load_record<kRecStage2, kRecStage3>(r, rp);
+            live = live && soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
+            if (!__any(live)) continue;
+#if GENDR_ABLATE == 2
+            if (live) alpha += q.frag;
+            continue;
+#endif
+            load_record<kRecStage3, REC>(r, rp);
+            if (!live) continue;
 
-            for (int i = 0; i < wn; i++) {
-                const int slot = lds.wlist[wave][i];
-                const float* r = s_rec + slot * REC;
-                Pair q;
-                if (!t.valid) continue;
-                if (!eval_pair<DIST, SQ>(q, r, t.xp, t.yp, a, dp)) continue;
+            // alpha, kernel.cu:791-803
+            if (alpha_func == kAlphaHard) {
+                if ((double)q.frag > 0.5) alpha = 1.f;
+            } else if constexpr (ALPHA > 0) {
+                alpha = TConorm<(ALPHA > 0 ? ALPHA : 1)>::fold(alpha, q.frag, a.p.aggr_alpha_t_conorm_p);
+            } else {
+                alpha = tconorm_fold_rt(alpha_func, alpha, q.frag, a.p.aggr_alpha_t_conorm_p);
+            }
 
-                // alpha, kernel.cu:791-803
-                if (alpha_func == kAlphaHard) {
-                    if ((double)q.frag > 0.5) alpha = 1.f;
-                } else if constexpr (ALPHA > 0) {
-                    alpha = TConorm<(ALPHA > 0 ? ALPHA : 1)>::fold(alpha, q.frag, a.p.aggr_alpha_t_conorm_p);
-                } else {
-                    alpha = tconorm_fold_rt(alpha_func, alpha, q.frag, a.p.aggr_alpha_t_conorm_p);
+            float wc[3];
+            const float zp = clip_and_depth(q, r, wc);
+            if (zp < a.p.near_ || zp > a.p.far_) continue;                       // :810
+#if GENDR_ABLATE == 3
+            alpha += zp;
+            continue;
+#endif
+
+            const long face_lin = (long)t.b * a.nf + fn;
+            const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
+            if (!rgb_soft) {                                                     // :815-822
+                if (zp < depth_min && inside_closed(q) && (a.p.double_side || front)) {
+                    depth_min = zp;
+                    face_min = fn;
+                    int own;
+                    sample_colour<TEXM>(col, own, wc, r, a, face_lin);
                 }
-
-                float wc[3];
-                const float zp = clip_and_depth(q, r, wc);
-                if (zp < a.p.near_ || zp > a.p.far_) continue;                       // :810
-
-                const int fn = range0 + lds.list[c0 + slot];
-                const long face_lin = (long)t.b * a.nf + fn;
-                const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
-                if (!rgb_soft) {                                                     // :815-822
-                    if (zp < depth_min && inside_closed(q.w) && (a.p.double_side || front)) {
-                        depth_min = zp;
-                        face_min = fn;
-                        int own;
-                        sample_colour<TEXM>(col, own, wc, r, a, face_lin);
-                    }
-                } else if (front || a.p.double_side) {                               // :824-838
-                    const float zn = (a.p.far_ - zp) / (a.p.far_ - a.p.near_);
-                    float edz = 1.f;
-                    if (zn > smax) {
-                        edz = expf((smax - zn) / gam);
-                        smax = zn;
-                    }
-                    const float ez = expf((zn - smax) / gam);
-                    ssum = edz * ssum + ez * q.frag;
-                    float c[3]; int own;
-                    sample_colour<TEXM>(c, own, wc, r, a, face_lin);
+            } else if (front || a.p.double_side) {                               // :824-838
+                const float zn = div_by(a.p.far_ - zp, a.r_zrange);
+                // exp_delta_zp and exp_z of :827-832: one of the two is exp(0) == 1 exactly
+                const bool deeper = zn > smax;
+                const float e = expf(div_by(deeper ? smax - zn : zn - smax, a.r_gamma));
+                const float edz = deeper ? e : 1.f;
+                const float ez = deeper ? 1.f : e;
+                if (deeper) smax = zn;
+                ssum = edz * ssum + ez * q.frag;
+                float cc[3]; int own;
+                sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) col[k] = edz * col[k] + ez * q.frag * c[k];
-                }
+                for (int k = 0; k < 3; k++) col[k] = edz * col[k] + ez * q.frag * cc[k];
             }
         }
-        if (range1 < a.nf) __syncthreads();              // list is rebuilt by the next range
     }
 
     if (!t.valid) return;
@@ -663,9 +720,9 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// wavefront sum with DPP adds (result valid in every lane via readlane 63)
+// wavefront sum with DPP adds; the total ends up in lane 63 (only lane 63 is meaningful)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v)
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
 {
     // quad swaps, half-row mirror, row mirror, then the two cross-row broadcasts of GFX9
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
@@ -674,7 +731,7 @@ __device__ __forceinline__ float wave_sum(float v)
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true));   // row_bcast:15 -> rows 1,3
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true));   // row_bcast:31 -> rows 2,3
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,16 +743,13 @@ template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderArgs a)
 {
     constexpr int REC = record_floats(TEXM);
-    constexpr int NG = GradSlots<TEXM>::n;       // 9 vertex components, then texture components kept in LDS
-    __shared__ __attribute__((aligned(16))) float s_rec[kRecCap * REC];
-    __shared__ float s_acc[kRecCap * NG];
-    __shared__ TileLds lds;
-
+    constexpr int NG = GradSlots<TEXM>::n;       // 9 vertex components, then texture components reduced per wave
+    constexpr int NT = NG > 9 ? NG - 9 : 1;
     TileCtx t;
-    tile_setup(t, a);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (!tile_setup(t, a)) return;
+    const int lane = threadIdx.x & 63;
     const long P = (long)a.is * a.is;
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift};
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
@@ -714,148 +768,136 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
         smax = a.aux[((long)t.b * 2 + 1) * P + t.pix];
     }
 
-    for (int range0 = 0; range0 < a.nf; range0 += kListCap) {
-        const int range1 = min(a.nf, range0 + kListCap);
-        const int count = scan_faces(a, t, lds, range0, range1);
-        for (int c0 = 0; c0 < count; c0 += kRecCap) {
-            const int n = min(kRecCap, count - c0);
-            if (c0 > 0) __syncthreads();
-            stage_records<REC>(a, t, lds, s_rec, range0, c0, n);
-            for (int e = threadIdx.x; e < n * NG; e += kThreads) s_acc[e] = 0.f;
-            __syncthreads();
-            const int wn = wave_refine<REC>(a, t, lds, s_rec, n);
+    const MaskPtr mrow = (MaskPtr)a.masks + (long)t.tile * a.chunks;
+    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
+    for (int c = 0; c < a.chunks; c++) {
+        unsigned long long w = mrow[c];
+        while (w) {
+            const int fn = c * 64 + __builtin_ctzll(w);
+            w &= w - 1;
+            const RecPtr rp = recs + (long)fn * REC;
+            const long face_lin = (long)t.b * a.nf + fn;
+            float r[REC];
+            load_record<0, 16>(r, rp);
+            bool live = t.valid && inside_box(r, t.xp, t.yp);
+            if (!__any(live)) continue;                      // whole wave outside the box: no further loads
+            Pair q;
+            barycentrics(q, r, t.xp, t.yp);
+            load_record<kRecStage2, kRecStage3>(r, rp);
+            live = live && soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
+            if (!__any(live)) continue;
+            load_record<kRecStage3, REC>(r, rp);
 
-            for (int i = 0; i < wn; i++) {
-                const int slot = lds.wlist[wave][i];
-                const float* r = s_rec + slot * REC;
-                const int fn = range0 + lds.list[c0 + slot];
-                const long face_lin = (long)t.b * a.nf + fn;
-
-                float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
-                float gt[NG > 9 ? NG - 9 : 1];     // texture partials kept in LDS
+            float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
+            float gt[NT];                      // texture partials reduced over the wave
 #pragma unroll
-                for (int k = 0; k < 9; k++) gv[k] = 0.f;
+            for (int k = 0; k < 9; k++) gv[k] = 0.f;
 #pragma unroll
-                for (int k = 0; k < (NG > 9 ? NG - 9 : 1); k++) gt[k] = 0.f;
+            for (int k = 0; k < NT; k++) gt[k] = 0.f;
 
-                Pair q;
-                bool live = t.valid && eval_pair<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
+            if (live) {
+                // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
+                float C_xy = 0.f;
+                float C_alpha = g[3];
+                if (alpha_func != kAlphaHard) {
+                    if constexpr (ALPHA > 0) C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    else                     C_alpha *= tconorm_grad_rt(alpha_func, out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                }
+                C_xy += C_alpha;
+
+                float wc[3];
+                const float zp = clip_and_depth(q, r, wc);
+                live = !(zp < a.p.near_ || zp > a.p.far_);                      // :994 drops the whole pair
                 if (live) {
-                    // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
-                    float C_xy = 0.f;
-                    float C_alpha = g[3];
-                    if (alpha_func != kAlphaHard) {
-                        if constexpr (ALPHA > 0) C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                        else                     C_alpha *= tconorm_grad_rt(alpha_func, out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                    }
-                    C_xy += C_alpha;
-
-                    float wc[3];
-                    const float zp = clip_and_depth(q, r, wc);
-                    live = !(zp < a.p.near_ || zp > a.p.far_);                      // :994 drops the whole pair
-                    if (live) {
-                        const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
-                        if (!rgb_soft) {                                            // :997-1004
-                            if ((float)fn == smax) {
-                                if constexpr (TEXM == kTexVertex) {
+                    const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
+                    if (!rgb_soft) {                                            // :997-1004
+                        if ((float)fn == smax) {
+                            if constexpr (TEXM == kTexVertex) {
 #pragma unroll
-                                    for (int k = 0; k < 3; k++)
+                                for (int k = 0; k < 3; k++)
 #pragma unroll
-                                        for (int j = 0; j < 3; j++) gt[3 * j + k] = wc[j] * g[k];
-                                } else {
-                                    float c[3]; int own;
-                                    sample_colour<TEXM>(c, own, wc, r, a, face_lin);
-                                    if (own >= 0) {
-                                        if constexpr (TEXM == kTexSurface1) {
+                                    for (int j = 0; j < 3; j++) gt[3 * j + k] = wc[j] * g[k];
+                            } else {
+                                float cc[3]; int own;
+                                sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
+                                if (own >= 0) {
+                                    if constexpr (TEXM == kTexSurface1) {
 #pragma unroll
-                                            for (int k = 0; k < 3; k++) gt[k] = g[k];
-                                        } else {
+                                        for (int k = 0; k < 3; k++) gt[k] = g[k];
+                                    } else {
 #pragma unroll
-                                            for (int k = 0; k < 3; k++)
-                                                unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, g[k]);
-                                        }
+                                        for (int k = 0; k < 3; k++)
+                                            unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, g[k]);
                                     }
                                 }
                             }
-                        } else if (front || a.p.double_side) {                      // :1006-1030
-                            const float zn = (a.p.far_ - zp) / (a.p.far_ - a.p.near_);
-                            const float zs = q.frag * expf((zn - smax) / gam) / ssum;   // :1010
-                            float c[3]; int own;
-                            sample_colour<TEXM>(c, own, wc, r, a, face_lin);
-                            float C_rgb = 0.f;
-#pragma unroll
-                            for (int k = 0; k < 3; k++) {
-                                if constexpr (TEXM == kTexVertex) {
-#pragma unroll
-                                    for (int j = 0; j < 3; j++) gt[3 * j + k] = zs * (wc[j] * g[k]);
-                                } else if constexpr (TEXM == kTexSurface1) {
-                                    if (own >= 0) gt[k] = zs * g[k];
-                                } else {
-                                    if (own >= 0) unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, zs * g[k]);
-                                }
-                                C_rgb += g[k] * (c[k] - out[k]);                    // :1021
-                            }
-                            C_rgb *= zs;                                            // :1023
-                            C_xy += C_rgb / q.frag;                                 // :1024
-                            const float C_z = C_rgb / gam / (a.p.near_ - a.p.far_) * zp * zp;   // :1026
-                            gv[2] = C_z * wc[0] / r[kRecVert + 2] / r[kRecVert + 2];
-                            gv[5] = C_z * wc[1] / r[kRecVert + 5] / r[kRecVert + 5];
-                            gv[8] = C_z * wc[2] / r[kRecVert + 8] / r[kRecVert + 8];
                         }
-
-                        // distance gradient, kernel.cu:1034-1052.  Heaviside: D' = 0 times uninitialised
-                        // values in the reference -> defined as exactly 0 here (DESIGN.md quirk i).
-                        if (dist != kHeaviside) {
-                            if constexpr (DIST >= 0) C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
-                            else                     C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
+                    } else if (front || a.p.double_side) {                      // :1006-1030
+                        const float zn = div_by(a.p.far_ - zp, a.r_zrange);
+                        const float zs = q.frag * expf(div_by(zn - smax, a.r_gamma)) / ssum;   // :1010
+                        float cc[3]; int own;
+                        sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
+                        float C_rgb = 0.f;
 #pragma unroll
-                            for (int k = 0; k < 3; k++) {
-                                const float wk = q.t[k] + q.w[k];
-                                if (squared) {
-                                    gv[3 * k + 0] = 2 * q.sign * C_xy * wk * q.dx;
-                                    gv[3 * k + 1] = 2 * q.sign * C_xy * wk * q.dy;
-                                } else {
-                                    const double nrm = fmax((double)sqrtf(q.dx * q.dx + q.dy * q.dy), 1e-6);
-                                    gv[3 * k + 0] = (float)((double)(q.sign * C_xy * wk * q.dx) / nrm);
-                                    gv[3 * k + 1] = (float)((double)(q.sign * C_xy * wk * q.dy) / nrm);
-                                }
+                        for (int k = 0; k < 3; k++) {
+                            if constexpr (TEXM == kTexVertex) {
+#pragma unroll
+                                for (int j = 0; j < 3; j++) gt[3 * j + k] = zs * (wc[j] * g[k]);
+                            } else if constexpr (TEXM == kTexSurface1) {
+                                if (own >= 0) gt[k] = zs * g[k];
+                            } else {
+                                if (own >= 0) unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, zs * g[k]);
+                            }
+                            C_rgb += g[k] * (cc[k] - out[k]);                   // :1021
+                        }
+                        C_rgb *= zs;                                            // :1023
+                        C_xy += C_rgb / q.frag;                                 // :1024
+                        const float C_z = div_by(div_by(C_rgb, a.r_gamma), a.r_nzrange) * zp * zp;   // :1026
+                        gv[2] = div_by(div_by(C_z * wc[0], rec_double(r, kRecRZ + 0)), rec_double(r, kRecRZ + 0));
+                        gv[5] = div_by(div_by(C_z * wc[1], rec_double(r, kRecRZ + 2)), rec_double(r, kRecRZ + 2));
+                        gv[8] = div_by(div_by(C_z * wc[2], rec_double(r, kRecRZ + 4)), rec_double(r, kRecRZ + 4));
+                    }
+
+                    // distance gradient, kernel.cu:1034-1052.  Heaviside: D' = 0 times uninitialised
+                    // values in the reference -> defined as exactly 0 here (DESIGN.md quirk i).
+                    if (dist != kHeaviside) {
+                        if constexpr (DIST >= 0) C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
+                        else                     C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
+                        const float tw[3] = {q.t0 + q.w0, q.t1 + q.w1, q.t2 + q.w2};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            if (squared) {
+                                gv[3 * k + 0] = 2 * q.sign * C_xy * tw[k] * q.dx;
+                                gv[3 * k + 1] = 2 * q.sign * C_xy * tw[k] * q.dy;
+                            } else {
+                                const double nrm = fmax((double)sqrtf(q.dx * q.dx + q.dy * q.dy), 1e-6);
+                                gv[3 * k + 0] = (float)((double)(q.sign * C_xy * tw[k] * q.dx) / nrm);
+                                gv[3 * k + 1] = (float)((double)(q.sign * C_xy * tw[k] * q.dy) / nrm);
                             }
                         }
                     }
                 }
-                if (!live) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) gv[k] = 0.f;
-#pragma unroll
-                    for (int k = 0; k < (NG > 9 ? NG - 9 : 1); k++) gt[k] = 0.f;
-                }
-                if (!__any(live)) continue;
-                // wavefront reduction, then one LDS atomic per component from lane 0
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const float s = wave_sum(gv[k]);
-                    if (lane == 0 && s != 0.f) atomicAdd(&s_acc[slot * NG + k], s);
-                }
-#pragma unroll
-                for (int k = 0; k < NG - 9; k++) {
-                    const float s = wave_sum(gt[k]);
-                    if (lane == 0 && s != 0.f) atomicAdd(&s_acc[slot * NG + 9 + k], s);
-                }
             }
-
-            __syncthreads();
-            // flush the tile's partial sums: one hardware fp32 atomic per (face, component)
-            for (int e = threadIdx.x; e < n * NG; e += kThreads) {
-                const float v = s_acc[e];
-                if (v != 0.f) {
-                    const int slot = e / NG, k = e - slot * NG;
-                    const long face_lin = (long)t.b * a.nf + range0 + lds.list[c0 + slot];
-                    if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
-                    else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
-                }
+            if (!__any(live)) continue;
+            if (!live) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) gv[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < NT; k++) gt[k] = 0.f;
+            }
+            // wavefront reduction: lane 63 ends up with every total and issues the atomics
+            // (one hardware fp32 atomic per (tile, face, component))
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const float s = wave_sum_to_lane63(gv[k]);
+                if (lane == 63 && s != 0.f) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, s);
+            }
+#pragma unroll
+            for (int k = 0; k < NG - 9; k++) {
+                const float s = wave_sum_to_lane63(gt[k]);
+                if (lane == 63 && s != 0.f) unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + k, s);
             }
         }
-        if (range1 < a.nf) __syncthreads();
     }
 }
 

@@ -40,7 +40,20 @@ struct DistParams {
     float scale;   // tau
     float shape;   // p of gamma
     float shift;   // shift (in units of tau) of the one-sided families
+    double rscale; // RN_double(1 / (double)scale), see div_by()
 };
+
+GENDR_HD DistParams make_dist_params(float scale, float shape, float shift)
+{
+    DistParams d = {scale, shape, shift, 1. / (double)scale};
+    return d;
+}
+
+// a / b for floats, given rb = RN_double(1 / (double)b):  RN_float(a / b) == (float)((double)a * rb) exactly
+// (a float quotient is never within 2^-49 relative of a float rounding midpoint; the double product is within
+// 2^-52 of a / b; 0, inf and NaN divisors behave as IEEE division).  Used for divisors that are uniform over
+// a wavefront: three fp64-rate instructions instead of the IEEE f32 division expansion.
+GENDR_HD float div_by(float a, double rb) { return (float)((double)a * rb); }
 
 GENDR_HD float quiet_nan() { return __builtin_nanf(""); }
 
@@ -67,20 +80,20 @@ template <> struct Dist<kHeaviside> {
 
 template <> struct Dist<kUniform> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :270-277
-        const float u = sign * x / d.scale;
+        const float u = div_by(sign * x, d.rscale);
         if (u < -1) return 0.f;
         if (u < 1) return (float)((double)(sign * x) * 0.5 / (double)d.scale + 0.5);
         return 1.f;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :391-392
-        const float u = sign * x / d.scale;
-        return (u > -1 && u < 1) ? 0.5f / d.scale : 0.f;
+        const float u = div_by(sign * x, d.rscale);
+        return (u > -1 && u < 1) ? div_by(0.5f, d.rscale) : 0.f;
     }
 };
 
 template <> struct Dist<kCubicHermite> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :282-290
-        const float u = sign * x / d.scale;
+        const float u = div_by(sign * x, d.rscale);
         if (u < -1) return 0.f;
         if (u < 1) {
             const float y = (float)((double)(sign * x) * 0.5 / (double)d.scale + 0.5);
@@ -89,7 +102,7 @@ template <> struct Dist<kCubicHermite> {
         return 1.f;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :397-402
-        const float u = sign * x / d.scale;
+        const float u = div_by(sign * x, d.rscale);
         if (u < -1.f || u > 1.f) return 0.f;
         return (float)(0.75 / (double)d.scale - 0.75 * (double)(x * x) / pow((double)d.scale, 3.));
     }
@@ -111,30 +124,30 @@ template <> struct Dist<kWigner> {
 };
 
 template <> struct Dist<kGaussian> {
-    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return norm_cdf(sign * x / d.scale); }   // :292-293
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return norm_cdf(div_by(sign * x, d.rscale)); }   // :292-293
     static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :404-405 (exp in double)
-        const double q = (double)(x / d.scale);
+        const double q = (double)div_by(x, d.rscale);
         return (float)(1. / (double)d.scale / sqrt(2. * kPi) * exp(-0.5 * q * q));
     }
 };
 
 template <> struct Dist<kLaplace> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :263-268
-        const float e = 0.5f * expf(-x / d.scale);          // 0.5 * e is exact in either precision
+        const float e = 0.5f * expf(div_by(-x, d.rscale));  // 0.5 * e is exact in either precision
         return sign < 0 ? e : 1.f - e;
     }
     static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :388-389
-        return (float)(0.5 / (double)d.scale * (double)expf(-x / d.scale));
+        return (float)(0.5 / (double)d.scale * (double)expf(div_by(-x, d.rscale)));
     }
 };
 
 template <> struct Dist<kLogistic> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :254-255
-        return (float)(1. / (1. + (double)expf(-sign * x / d.scale)));
+        return (float)(1. / (1. + (double)expf(div_by(-sign * x, d.rscale))));
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :378-380
         const float y = cdf(sign, x, d);
-        return y * (1 - y) / d.scale;
+        return div_by(y * (1 - y), d.rscale);
     }
 };
 
@@ -186,14 +199,14 @@ template <bool REV> struct ExponentialFamily {                                  
         if (!REV) { if (sign * x + d.shift * d.scale < 0.f) return 0.f; }
         else      { if (sign * x - d.shift * d.scale > 0.f) return 1.f; }
         const float xs = shifted<REV>(sign, x, d);
-        const float y = 1.f - expf(-xs / d.scale);
+        const float y = 1.f - expf(div_by(-xs, d.rscale));
         return REV ? 1.f - y : y;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {
         if (!REV) { if (sign * x + d.shift * d.scale < 0.f) return 0.f; }
         else      { if (sign * x - d.shift * d.scale > 0.f) return 0.f; }
         const float xs = shifted<REV>(sign, x, d);
-        return (float)(1. / (double)d.scale * (double)expf(-xs / d.scale));
+        return (float)(1. / (double)d.scale * (double)expf(div_by(-xs, d.rscale)));
     }
 };
 template <> struct Dist<kExponential> : ExponentialFamily<false> {};
@@ -205,14 +218,15 @@ template <bool REV> struct GammaFamily {                                        
         if (!REV) { if (sign * x + d.shift * d.scale <= 0.f) return 0.f; }
         else      { if (sign * x - d.shift * d.scale >= 0.f) return 1.f; }
         const float xs = shifted<REV>(sign, x, d);
-        if ((double)(xs / d.scale) > kGammaCut) return REV ? 0.f : 1.f;
+        const float xr = div_by(xs, d.rscale);               // xs / scale, used 34 times below
+        if ((double)xr > kGammaCut) return REV ? 0.f : 1.f;
         float kummers = (float)(1. / tgamma((double)d.shape + 1.));
         float factor = kummers;
         for (int i = 1; i < kGammaSteps; i++) {              // 32-term Kummer series, float
-            factor *= xs / d.scale / (d.shape + i);
+            factor *= xr / (d.shape + i);
             kummers += factor;
         }
-        const float y = powf(xs / d.scale, d.shape) * expf(-xs / d.scale) * kummers;
+        const float y = powf(xr, d.shape) * expf(div_by(-xs, d.rscale)) * kummers;
         return REV ? 1.f - y : y;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // explicit double in the reference

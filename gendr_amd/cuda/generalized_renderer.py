@@ -65,8 +65,8 @@ def backward_render(faces, textures, soft_colors, faces_info, aggrs_info, grad_f
     B, nf = faces.shape[:2]
     T = textures.shape[2]
     f9 = faces.reshape(B, nf, 9)
-    records = torch.empty((max(B * nf, 1), L.gendr_face_record_floats(p.texture_type, T)),
-                          dtype=torch.float32, device=faces.device)
+    records = torch.empty((max(int(L.gendr_workspace_bytes(B, nf, T, ctypes.byref(p))), 256),),
+                          dtype=torch.uint8, device=faces.device)
     with torch.cuda.device(faces.device):
         check(L.gendr_face_setup(_ptr(f9), _ptr(textures), _ptr(records), B, nf, T, ctypes.byref(p), _stream_ptr()),
               'gendr_face_setup')

@@ -143,8 +143,8 @@ def native_forward(faces, textures, params, rgba=None, aggrs_info=None):
         rgba = torch.empty((B, 4, isz, isz), dtype=torch.float32, device=dev)
     if aggrs_info is None:
         aggrs_info = torch.empty((B, 2, isz, isz), dtype=torch.float32, device=dev)
-    rec_floats = L.gendr_face_record_floats(params.texture_type, T)
-    records = torch.empty((max(B * nf, 1), rec_floats), dtype=torch.float32, device=dev)
+    records = torch.empty((max(int(L.gendr_workspace_bytes(B, nf, T, ctypes.byref(params))), 256),),
+                          dtype=torch.uint8, device=dev)
     ev = PROFILE_EVENTS
     with torch.cuda.device(dev):
         if ev is not None:

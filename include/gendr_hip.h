@@ -31,7 +31,7 @@ enum {
     GENDR_E_DIST_PARAM    = -7,  /* dist_scale < 0, dist_eps < 1 (functional/renderer.py:96,101), gamma shape < 0 (kernel.cu:296) */
     GENDR_E_TCONORM_PARAM = -8,  /* invalid t-conorm p (kernel.cu:491,501,512,522,534,552) */
     GENDR_E_LAUNCH        = -9,  /* hipGetLastError() != hipSuccess after a launch */
-    GENDR_E_WORKSPACE     = -10  /* face_records buffer missing */
+    GENDR_E_WORKSPACE     = -10  /* workspace buffer missing */
 };
 
 /* Scalar options of forward_render / backward_render, in the reference's order
@@ -63,17 +63,20 @@ typedef struct gendr_params {
     int   cull;                    /* 1: exact tile culling (default), 0: visit every (pixel, face) pair */
 } gendr_params;
 
-/* Floats per face in the face-record workspace (depends on the texture layout). */
-int gendr_face_record_floats(int texture_type, int T);
+/* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward
+ * reads: per-face cull boxes and records (this build's replacement for `faces_info`) plus the
+ * per-tile face masks of the exact culling.  0 on invalid arguments. */
+unsigned long long gendr_workspace_bytes(int B, int nf, int T, const gendr_params* p);
 
 /* Validates the option set exactly as the reference's asserts / device checks do. */
 int gendr_validate(const gendr_params* p, int B, int nf, int T);
 
 /* Per-face preprocessing into this build's record layout (replaces forward_render_inv_cuda_kernel,
- * kernel.cu:620-676, launched at :1100-1109).  gendr_forward() runs it itself; it is exported for
- * callers that hold only `faces` when they reach backward (the pybind-shaped backward_render).
- *   face_records [B*nf, gendr_face_record_floats()] out */
-int gendr_face_setup(const float* faces, const float* textures, float* face_records,
+ * kernel.cu:620-676, launched at :1100-1109) followed by the tile binning of the exact culling.
+ * gendr_forward() runs it itself; it is exported for callers that hold only `faces` when they reach
+ * backward (the pybind-shaped backward_render).
+ *   workspace [gendr_workspace_bytes()] out, 256-byte aligned */
+int gendr_face_setup(const float* faces, const float* textures, void* workspace,
                      int B, int nf, int T, const gendr_params* p, void* stream);
 
 /* replaces forward_render (generalized_renderer_cuda.cpp:74-127 -> kernel.cu:1071-1152).
@@ -81,16 +84,15 @@ int gendr_face_setup(const float* faces, const float* textures, float* face_reco
  *   textures     [B,nf,T,3]  in
  *   rgba         [B,4,is,is] out  (in/out when background_from_buffer)   = `soft_colors`
  *   aggrs_info   [B,2,is,is] out  (softmax_sum, softmax_max) or (depth_min, face_index_min)
- *   face_records [B,nf,gendr_face_record_floats()] out, workspace kept for backward
- *                (this build's replacement for `faces_info`). */
+ *   workspace    [gendr_workspace_bytes()] out, kept by the caller for backward */
 int gendr_forward(const float* faces, const float* textures, float* rgba, float* aggrs_info,
-                  float* face_records, int B, int nf, int T, const gendr_params* p, void* stream);
+                  void* workspace, int B, int nf, int T, const gendr_params* p, void* stream);
 
 /* replaces backward_render (generalized_renderer_cuda.cpp:130-192 -> kernel.cu:1155-1227).
  *   grad_faces [B,nf,9] and grad_textures [B,nf,T,3] must be zero-filled by the
  *   caller (functional/renderer.py:191-196); gradients are accumulated into them. */
 int gendr_backward(const float* faces, const float* textures, const float* rgba, const float* aggrs_info,
-                   const float* face_records, const float* grad_rgba,
+                   const void* workspace, const float* grad_rgba,
                    float* grad_faces, float* grad_textures,
                    int B, int nf, int T, const gendr_params* p, void* stream);
 

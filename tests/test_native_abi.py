@@ -75,10 +75,13 @@ def test_validate_shapes(native_lib):
     assert native_lib.gendr_validate(None, 1, 1, 1) == -1
 
 
-def test_record_floats(native_lib):
-    assert native_lib.gendr_face_record_floats(0, 1) == 48
-    assert native_lib.gendr_face_record_floats(1, 3) == 52
-    assert native_lib.gendr_face_record_floats(0, 4) == 40
+def test_workspace_bytes(native_lib):
+    p = _params(image_size=256)
+    # boxes 16 B + record 208 B per face, masks 8 B per (8x8 tile, 64-face chunk); every part 256-byte aligned
+    n = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(p))
+    assert n == 2 * 1280 * 16 + 2 * 1280 * 208 + 2 * 32 * 32 * 20 * 8
+    assert native_lib.gendr_workspace_bytes(2, 1280, 3, ctypes.byref(_params(image_size=256, texture_type='vertex'))) > n
+    assert native_lib.gendr_workspace_bytes(2, 1280, 0, ctypes.byref(p)) == 0
 
 
 def test_cull_radius_is_conservative(native_lib, oracle_mod):
