@@ -87,27 +87,29 @@ __device__ __forceinline__ double rec_double(const float* r, int k)
 // face record layout (floats).  Geometry part is common; the tail depends on the texture mode.
 // ---------------------------------------------------------------------------------------------
 // Ordered by the stage of the inner loop that consumes it, so that each stage is one contiguous scalar load:
-//   stage 1 [0,16)   box + barycentric matrix + flags          -> per-lane box test, barycentrics
-//   stage 2 [16,38)  edge data + vertex x,y                     -> point-to-triangle distance
-//   stage 3 [38,REC) reciprocal vertex depths + texels          -> depth, colour
+//   stage 1 [0,20)   box + barycentric matrix + flags + edge cull -> per-lane box / edge tests, barycentrics
+//   stage 2 [20,42)  edge data + vertex x,y                     -> point-to-triangle distance
+//   stage 3 [42,REC) reciprocal vertex depths + texels          -> depth, colour
 // Divisors that are uniform over the wavefront are stored as correctly rounded DOUBLE reciprocals
 // (see div_by()).
 constexpr int kRecBox   = 0;    // xlo, xhi, ylo, yhi : pixel centres outside are skipped
 constexpr int kRecInv   = 4;    // inv[9]   (kernel.cu:645-657)
 constexpr int kRecBits  = 13;   // int bits: 1,2,4 = first obtuse corner 0,1,2 (:667-675); 8 = front side (:56-58)
-constexpr int kRecEdge  = 16;   // A[3][3]  A[k][j] = sym[k][j] - sym[(k+1)%3][j]  (kernel.cu:95-97,146-148)
-constexpr int kRecRDen  = 26;   // 3 doubles: 1 / Dn[k],  Dn[k] = A[k][k] - A[k][(k+1)%3]  (denominator of :99,:150)
-constexpr int kRecXY    = 32;   // x0 y0 x1 y1 x2 y2
-constexpr int kRecRZ    = 38;   // 3 doubles: 1 / z_k   (:809, :1027-1029)
-constexpr int kRecTex   = 44;   // TEXM 0: own rgb, next-face rgb ; TEXM 1: 3 vertex colours ; TEXM 2: nothing
-constexpr int kRecStage2 = 16, kRecStage3 = 38;
+constexpr int kRecWCull = 14;   // wcull[3]: a pixel whose computed barycentric w_k is below wcull_k lies farther than
+                                // the cull radius beyond the edge opposite vertex k -> the reference skips the pair
+constexpr int kRecEdge  = 20;   // A[3][3]  A[k][j] = sym[k][j] - sym[(k+1)%3][j]  (kernel.cu:95-97,146-148)
+constexpr int kRecRDen  = 30;   // 3 doubles: 1 / Dn[k],  Dn[k] = A[k][k] - A[k][(k+1)%3]  (denominator of :99,:150)
+constexpr int kRecXY    = 36;   // x0 y0 x1 y1 x2 y2
+constexpr int kRecRZ    = 42;   // 3 doubles: 1 / z_k   (:809, :1027-1029)
+constexpr int kRecTex   = 48;   // TEXM 0: own rgb, next-face rgb ; TEXM 1: 3 vertex colours ; TEXM 2: nothing
+constexpr int kRecStage1 = 20, kRecStage3 = 42;
 
 // texture modes of the kernels
 constexpr int kTexSurface1 = 0;   // texture_type surface, T == 1 (default Mesh texture): texels staged in the record
 constexpr int kTexVertex   = 1;   // texture_type vertex (T == 3): 9 floats staged in the record
 constexpr int kTexSurfaceN = 2;   // texture_type surface, T = R*R > 1: texels read from HBM/L2 per pair
 
-__host__ __device__ constexpr int record_floats(int texm) { return texm == kTexSurface1 ? 52 : (texm == kTexVertex ? 56 : 44); }
+__host__ __device__ constexpr int record_floats(int texm) { return texm == kTexSurface1 ? 56 : (texm == kTexVertex ? 60 : 48); }
 
 constexpr int kTile    = 8;     // one wavefront renders an 8x8 pixel tile
 constexpr int kThreads = 256;   // 4 independent wave-tiles per workgroup
@@ -206,37 +208,65 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const float ymax = fmaxf(fmaxf(f[1], f[4]), f[7]), ymin = fminf(fminf(f[1], f[4]), f[7]);
     // the reference's own test: x > max + thr || x < min - thr ...  (same float operations)
     float xhi = xmax + sthr, xlo = xmin - sthr, yhi = ymax + sthr, ylo = ymin - sthr;
+    float wcull[3] = {-INFINITY, -INFINITY, -INFINITY};
 
     if (cull_r < INFINITY) {
-        // Bound E on |computed distance - true distance| for pixel centres in [-1,1]^2, from the measured
-        // difference between the float inverse the loop will use and a double-precision inverse, plus the
-        // rounding of the barycentric and distance evaluations.  A pixel farther than cull_r + E from the
-        // face's bounding box cannot pass the reference's skip tests (DESIGN.md "exact culling").
+        // Bound E on (true distance - computed distance) for pixel centres q = (x, y, 1), |x|,|y| <= 1.
+        // The loop computes w = inv32 q (rounded) and the vector dis = sum_k (t_k - w_k) v_k with the closest
+        // point c = sum_k t_k v_k on the triangle's boundary, i.e. dis = c - p_w with p_w = sum_k w_k v_k.
+        // With V = [x_k; y_k; 1] and the exact inverse inv64 = V^-1:  p_w - p = V_xy (inv32 - inv64) q  + rounding.
+        // The linear part is evaluated as a matrix product in double (the cancellation sum_k w_k v_k = p survives,
+        // which matters for sliver faces whose float inverse is off by percents); rounding of every float
+        // operation is bounded by u = 2^-24 relative to its result.  Likewise sum_k w_k = 1 + (1^T delta) q,
+        // which bounds how far a pixel that the loop takes for an inside pixel can be from the triangle.
+        // A pixel centre farther than cull_r + E from the face's bounding box cannot pass the reference's skip
+        // tests (DESIGN.md "exact culling"); tests/test_gpu_parity.py::test_culling_is_exact checks it bit for bit.
         const double X0 = f[0], Y0 = f[1], X1 = f[3], Y1 = f[4], X2 = f[6], Y2 = f[7];
         const double det = X2 * (Y0 - Y1) + X0 * (Y1 - Y2) + X1 * (Y2 - Y0);
         const double adj[9] = {
             Y1 - Y2, X2 - X1, X1 * Y2 - X2 * Y1,
             Y2 - Y0, X0 - X2, X2 * Y0 - X0 * Y2,
             Y0 - Y1, X1 - X0, X0 * Y1 - X1 * Y0};
-        const double eps = 1.1920928955078125e-07;
+        const double u = 5.9604644775390625e-08;
+        const double vx[3] = {X0, X1, X2}, vy[3] = {Y0, Y1, Y2};
         const double vn[3] = {fabs(X0) + fabs(Y0), fabs(X1) + fabs(Y1), fabs(X2) + fabs(Y2)};
-        double E = 0., wmax = 0.;
+        double delta[9], W[3], dw[3], wmax = 0.;
         for (int k = 0; k < 3; k++) {
-            double dinv = 0., wk = 0.;
+            W[k] = 0.; dw[k] = 0.;
             for (int j = 0; j < 3; j++) {
-                dinv += fabs((double)g.inv[3 * k + j] - adj[3 * k + j] / det);
-                wk += fabs((double)g.inv[3 * k + j]);
+                delta[3 * k + j] = (double)g.inv[3 * k + j] - adj[3 * k + j] / det;
+                W[k] += fabs((double)g.inv[3 * k + j]);
+                dw[k] += fabs(delta[3 * k + j]);
             }
-            E += (dinv + 4. * eps * wk) * vn[k];
-            wmax = fmax(wmax, wk);
+            dw[k] += 4. * u * W[k];                 // bound on |computed w_k - true w_k| over the image
+            wmax = fmax(wmax, W[k]);
         }
-        E = 2. * E + 8. * eps * (1. + wmax) * (vn[0] + vn[1] + vn[2]);
+        double gx = 0., gy = 0., gs = 0.;
+        for (int j = 0; j < 3; j++) {
+            double ax = 0., ay = 0., as = 0.;
+            for (int k = 0; k < 3; k++) { ax += vx[k] * delta[3 * k + j]; ay += vy[k] * delta[3 * k + j]; as += delta[3 * k + j]; }
+            gx += fabs(ax); gy += fabs(ay); gs += fabs(as);
+        }
+        const double vmax = fmax(vn[0], fmax(vn[1], vn[2]));
+        double E = sqrt(gx * gx + gy * gy)                                           // |V_xy delta q|
+                 + 4. * u * (W[0] * vn[0] + W[1] * vn[1] + W[2] * vn[2])              // rounding of w_k, carried by v_k
+                 + 4. * u * ((1. + W[0]) * vn[0] + (1. + W[1]) * vn[1] + (1. + W[2]) * vn[2])   // rounding of (t_k - w_k) v_k sums
+                 + (gs + 4. * u * (W[0] + W[1] + W[2])) * vmax;                       // |sum_k w_k - 1| scaling of an "inside" p_w
+        E *= 2.;                                                                       // safety factor
         const double Rf = (double)cull_r * (1. + 1. / 1024.) + E;
         if (Rf == Rf && Rf < 1e30) {   // finite: otherwise keep the reference box only
             xhi = fminf(xhi, round_up((double)xmax + Rf));
             xlo = fmaxf(xlo, round_down((double)xmin - Rf));
             yhi = fminf(yhi, round_up((double)ymax + Rf));
             ylo = fmaxf(ylo, round_down((double)ymin - Rf));
+            // Edge test in barycentric units: true w_k = -(distance beyond the edge opposite vertex k) / H_k,
+            // H_k = |det| / |v_{k+1} - v_{k+2}|.  computed w_k < wcull_k  =>  true distance > Rf.
+            const double ex[3] = {X1 - X2, X2 - X0, X0 - X1}, ey[3] = {Y1 - Y2, Y2 - Y0, Y0 - Y1};
+            for (int k = 0; k < 3; k++) {
+                const double len = sqrt(ex[k] * ex[k] + ey[k] * ey[k]);
+                const double wc = -(Rf * len / fabs(det)) * (1. + 1. / 1024.) - dw[k];
+                if (wc == wc && wc > -1e30) wcull[k] = round_down(wc);
+            }
         }
     }
 
@@ -248,7 +278,8 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
 #pragma unroll
     for (int k = 0; k < 9; k++) r[kRecInv + k] = g.inv[k];
     r[kRecBits] = __int_as_float(g.obt | (g.front << 3));
-    r[14] = 0.f; r[15] = 0.f;
+    r[kRecWCull + 0] = wcull[0]; r[kRecWCull + 1] = wcull[1]; r[kRecWCull + 2] = wcull[2];
+    r[17] = 0.f; r[18] = 0.f; r[19] = 0.f;
     double* rden = reinterpret_cast<double*>(r + kRecRDen);
     double* rz = reinterpret_cast<double*>(r + kRecRZ);
 #pragma unroll
@@ -261,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         r[kRecXY + 2 * k] = f[3 * k]; r[kRecXY + 2 * k + 1] = f[3 * k + 1];
         rz[k] = 1. / (double)f[3 * k + 2];
     }
-    r[25] = 0.f;
+    r[29] = 0.f;
     if (TEXM == kTexSurface1) {
         const long nxt = (i + 1 < total_faces) ? i + 1 : i;   // reference reads the next face's texel (:179-182); none after the last
 #pragma unroll
@@ -500,6 +531,11 @@ __device__ __forceinline__ bool inside_box(const float* r, float xp, float yp)
 {
     return !(xp > r[kRecBox + 1] || xp < r[kRecBox + 0] || yp > r[kRecBox + 3] || yp < r[kRecBox + 2]);
 }
+// exact edge reject (see kRecWCull); false for NaN barycentrics so that those reach the reference's own logic
+__device__ __forceinline__ bool beyond_an_edge(const Pair& q, const float* r)
+{
+    return q.w0 < r[kRecWCull + 0] || q.w1 < r[kRecWCull + 1] || q.w2 < r[kRecWCull + 2];
+}
 __device__ __forceinline__ void barycentrics(Pair& q, const float* r, float xp, float yp)   // :39-43
 {
     q.w0 = r[kRecInv + 0] * xp + r[kRecInv + 1] * yp + r[kRecInv + 2];
@@ -639,7 +675,7 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
             w &= w - 1;
             const RecPtr rp = recs + (long)fn * REC;
             float r[REC];
-            load_record<0, 16>(r, rp);
+            load_record<0, kRecStage1>(r, rp);
             bool live = t.valid && inside_box(r, t.xp, t.yp);
             if (!__any(live)) continue;                      // whole wave outside the box: no further loads
 #if GENDR_ABLATE == 1
@@ -648,7 +684,9 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
 #endif
             Pair q;
             barycentrics(q, r, t.xp, t.yp);
-            load_record<kRecStage2, kRecStage3>(r, rp);
+            live = live && !beyond_an_edge(q, r);
+            if (!__any(live)) continue;                      // whole wave beyond an edge by more than the cull radius
+            load_record<kRecStage1, kRecStage3>(r, rp);
             live = live && soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
             if (!__any(live)) continue;
 #if GENDR_ABLATE == 2
@@ -778,12 +816,14 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             const RecPtr rp = recs + (long)fn * REC;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
-            load_record<0, 16>(r, rp);
+            load_record<0, kRecStage1>(r, rp);
             bool live = t.valid && inside_box(r, t.xp, t.yp);
             if (!__any(live)) continue;                      // whole wave outside the box: no further loads
             Pair q;
             barycentrics(q, r, t.xp, t.yp);
-            load_record<kRecStage2, kRecStage3>(r, rp);
+            live = live && !beyond_an_edge(q, r);
+            if (!__any(live)) continue;                      // whole wave beyond an edge by more than the cull radius
+            load_record<kRecStage1, kRecStage3>(r, rp);
             live = live && soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
             if (!__any(live)) continue;
             load_record<kRecStage3, REC>(r, rp);

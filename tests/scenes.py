@@ -30,6 +30,27 @@ def soup(B=2, nf=48, seed=0, T=1, vertex_tex=False):
     return fv, tex
 
 
+def slivers(B=2, nf=72, seed=0, T=1, vertex_tex=False):
+    """Grazing / nearly degenerate triangles of every thinness (what a closed mesh shows at its silhouette):
+    the float inverse of such faces is wrong by percents, which is exactly where a culling margin can fail."""
+    rs = np.random.RandomState(seed + 11)
+    fv = np.zeros((B, nf, 3, 3), np.float32)
+    for b in range(B):
+        a = rs.uniform(-0.8, 0.8, (nf, 2))
+        ang = rs.uniform(0, 2 * np.pi, nf)
+        length = rs.uniform(0.02, 0.6, nf)
+        d = np.stack([np.cos(ang), np.sin(ang)], -1)
+        n = np.stack([-d[:, 1], d[:, 0]], -1)
+        thin = 10.0 ** rs.uniform(-7.5, -2.0, nf)             # height of the third vertex over the long edge
+        bpt = a + d * length[:, None]
+        cpt = a + d * (length * rs.uniform(0.05, 0.95, nf))[:, None] + n * (thin * rs.choice([-1, 1], nf))[:, None]
+        fv[b, :, 0, :2], fv[b, :, 1, :2], fv[b, :, 2, :2] = a, bpt, cpt
+        fv[b, :, :, 2] = rs.uniform(1.5, 5.0, (nf, 3))
+        fv[b, ::7, :, :2] += 1.5                                # some partly / fully outside the viewport
+    tex = rs.uniform(0, 1, (B, nf, 3 if vertex_tex else T, 3)).astype(np.float32)
+    return fv, tex
+
+
 def sphere(B=2, subdivisions=1, vertex_tex=False, T=1, seed=0):
     """Closed icosphere seen from the benchmark's camera ring (grazing faces at the silhouette)."""
     import torch

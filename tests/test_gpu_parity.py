@@ -13,7 +13,7 @@ import scenes
 
 pytestmark = pytest.mark.gpu
 
-SCENES = {'soup': (scenes.soup, 48), 'sphere': (scenes.sphere, 64)}
+SCENES = {'soup': (scenes.soup, 48), 'sphere': (scenes.sphere, 64), 'slivers': (scenes.slivers, 64)}
 
 
 def _scene(scene, opts):
