@@ -639,19 +639,89 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 }
 
 // ---------------------------------------------------------------------------------------------
+// pair compaction (shared by forward and backward)
+//
+// Measured on the headline scene: a face touches only ~14 of a tile's 64 pixels, so evaluating "one face per
+// loop iteration, lane = pixel" leaves ~78 % of the lanes idle in the expensive stages.  Instead:
+//   phase A  (lane = pixel, one iteration per listed face, cheap): box test, barycentrics, edge reject; the
+//            surviving (pixel, face) pairs are appended -- in ascending (face, pixel) order -- to a
+//            wavefront-private list in LDS, together with the face's ballot mask;
+//   phase B  (lane = pair, dense): every lane fetches ITS pair's face record from L2 and runs the distance,
+//            CDF, clip/depth and colour stages; results go back to LDS;
+//   phase C  forward : lane = pixel again; faces of the batch are walked in ascending order and each pixel folds
+//                      its own pair's result (t-conorm fold, z-buffer / online softmax) -- the reference's order;
+//            backward: nothing sequential is left; gradients are summed per face with LDS atomics and leave the
+//                      CU as one hardware fp32 atomic per (tile batch, face, component).
+// Everything is wavefront-local: no barriers.
+// ---------------------------------------------------------------------------------------------
+struct PairRec {           // 32 bytes
+    float w0, w1, w2;      // barycentrics of the pixel w.r.t. the face (:39-43)
+    float xp, yp;          // pixel centre
+    int   code;            // (face slot in the batch << 8) | pixel lane
+    int   pad0, pad1;
+};
+struct FaceEnt {           // 16 bytes
+    int fn;                // face index inside the batch item
+    int base;              // index of the face's first pair in the batch
+    unsigned long long mask;   // ballot of the pixels (lanes) that own a pair of this face
+};
+constexpr int kFlagContrib = 1;   // passed :769 and :784 -> folds into alpha
+constexpr int kFlagDepthOk = 2;   // near <= zp <= far (:810)
+constexpr int kFlagRgb     = 4;   // eligible for the RGB aggregation (:816 resp. :825)
+
+// per-lane copy of the record fields phase B needs (stage 2 and 3 plus the flag word), 16-byte vector loads
+template <int REC>
+__device__ __forceinline__ void gather_record(float* r, const float* __restrict__ rec)
+{
+    const float4* src = reinterpret_cast<const float4*>(rec);
+#pragma unroll
+    for (int q = 3; q < REC / 4; q++) {             // floats [12, REC): bits live in [13]
+        const float4 v = src[q];
+        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+}
+
+// phase A for one listed face; returns the ballot of surviving lanes (0 = nothing to do)
+template <int REC>
+__device__ __forceinline__ unsigned long long collect_pairs(const TileCtx& t, RecPtr rp, Pair& q)
+{
+    float r[REC];
+    load_record<0, kRecStage1>(r, rp);
+    bool live = t.valid && inside_box(r, t.xp, t.yp);
+    if (!__any(live)) return 0ull;                   // whole wave outside the box
+    barycentrics(q, r, t.xp, t.yp);
+    live = live && !beyond_an_edge(q, r);
+    return __ballot(live);
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+struct FwdRes {            // 32 bytes: what phase C needs from a pair
+    float frag;            // soft fragment D
+    float z;               // zp (hard RGB) or zn (softmax)
+    float c0, c1, c2;      // sampled colour
+    int   flags;
+    int   pad0, pad1;
+};
+
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderArgs a)
 {
     constexpr int REC = record_floats(TEXM);
+    constexpr int WAVES = kThreads / 64;
+    __shared__ __attribute__((aligned(16))) PairRec s_pair[WAVES][64];
+    __shared__ __attribute__((aligned(16))) FwdRes  s_res[WAVES][64];
+    __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
+
     TileCtx t;
     if (!tile_setup(t, a)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const long P = (long)a.is * a.is;
     const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
-    const float gam = a.p.aggr_rgb_gamma;
 
     // per-pixel state, kernel.cu:728-740
     float bg[3];
@@ -666,6 +736,87 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
     float depth_min = 10000000.f;
     int face_min = -1;
 
+    const float* recs_g = a.records + (long)t.b * a.nf * REC;
+    int npairs = 0, nfaces = 0;
+
+    auto run_batch = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase B: one pair per lane
+        if (lane < npairs) {
+            const PairRec pr = s_pair[wave][lane];
+            const int fn = s_face[wave][pr.code >> 8].fn;
+            const long face_lin = (long)t.b * a.nf + fn;
+            float r[REC];
+            gather_record<REC>(r, recs_g + (long)fn * REC);
+            Pair q;
+            q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
+            FwdRes res;
+            res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.pad0 = res.pad1 = 0;
+            if (soft_fragment<DIST, SQ>(q, r, pr.xp, pr.yp, a, dp)) {
+                res.flags = kFlagContrib;
+                res.frag = q.frag;
+                float wc[3];
+                const float zp = clip_and_depth(q, r, wc);
+                if (!(zp < a.p.near_ || zp > a.p.far_)) {                         // :810
+                    res.flags |= kFlagDepthOk;
+                    const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
+                    const bool eligible = rgb_soft ? (front || a.p.double_side)                         // :825
+                                                   : (inside_closed(q) && (a.p.double_side || front));  // :816
+                    if (eligible) {
+                        res.flags |= kFlagRgb;
+                        res.z = rgb_soft ? div_by(a.p.far_ - zp, a.r_zrange) : zp;   // zp_norm (:826) or zp
+                        float cc[3]; int own;
+                        sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
+                        res.c0 = cc[0]; res.c1 = cc[1]; res.c2 = cc[2];
+                    }
+                }
+            }
+            s_res[wave][lane] = res;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase C: per pixel, faces in ascending order
+        for (int s = 0; s < nfaces; s++) {
+            const FaceEnt fe = s_face[wave][s];
+            const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(fe.mask >> 32)) << 32)
+                                       | (unsigned)__builtin_amdgcn_readfirstlane((int)fe.mask);
+            const int base = __builtin_amdgcn_readfirstlane(fe.base);
+            const int fn = __builtin_amdgcn_readfirstlane(fe.fn);
+            if (!((m >> lane) & 1ull)) continue;
+            const FwdRes res = s_res[wave][base + __popcll(m & lt)];
+            if (!(res.flags & kFlagContrib)) continue;
+            // alpha, kernel.cu:791-803
+            if (alpha_func == kAlphaHard) {
+                if ((double)res.frag > 0.5) alpha = 1.f;
+            } else if constexpr (ALPHA > 0) {
+                alpha = TConorm<(ALPHA > 0 ? ALPHA : 1)>::fold(alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
+            } else {
+                alpha = tconorm_fold_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
+            }
+            if (!(res.flags & kFlagRgb)) continue;
+            if (!rgb_soft) {                                                     // :815-822
+                if (res.z < depth_min) {
+                    depth_min = res.z;
+                    face_min = fn;
+                    col[0] = res.c0; col[1] = res.c1; col[2] = res.c2;
+                }
+            } else {                                                             // :824-838
+                const float zn = res.z;
+                // exp_delta_zp and exp_z of :827-832: one of the two is exp(0) == 1 exactly
+                const bool deeper = zn > smax;
+                const float e = expf(div_by(deeper ? smax - zn : zn - smax, a.r_gamma));
+                const float edz = deeper ? e : 1.f;
+                const float ez = deeper ? 1.f : e;
+                if (deeper) smax = zn;
+                ssum = edz * ssum + ez * res.frag;
+                col[0] = edz * col[0] + ez * res.frag * res.c0;
+                col[1] = edz * col[1] + ez * res.frag * res.c1;
+                col[2] = edz * col[2] + ez * res.frag * res.c2;
+            }
+        }
+        npairs = 0;
+        nfaces = 0;
+    };
+
     const MaskPtr mrow = (MaskPtr)a.masks + (long)t.tile * a.chunks;
     const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
     for (int c = 0; c < a.chunks; c++) {
@@ -673,71 +824,27 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
         while (w) {
             const int fn = c * 64 + __builtin_ctzll(w);
             w &= w - 1;
-            const RecPtr rp = recs + (long)fn * REC;
-            float r[REC];
-            load_record<0, kRecStage1>(r, rp);
-            bool live = t.valid && inside_box(r, t.xp, t.yp);
-            if (!__any(live)) continue;                      // whole wave outside the box: no further loads
-#if GENDR_ABLATE == 1
-            if (live) alpha += r[kRecInv];
-            continue;
-#endif
             Pair q;
-            barycentrics(q, r, t.xp, t.yp);
-            live = live && !beyond_an_edge(q, r);
-            if (!__any(live)) continue;                      // whole wave beyond an edge by more than the cull radius
-            load_record<kRecStage1, kRecStage3>(r, rp);
-            live = live && soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
-            if (!__any(live)) continue;
-#if GENDR_ABLATE == 2
-            if (live) alpha += q.frag;
-            continue;
-#endif
-            load_record<kRecStage3, REC>(r, rp);
-            if (!live) continue;
-
-            // alpha, kernel.cu:791-803
-            if (alpha_func == kAlphaHard) {
-                if ((double)q.frag > 0.5) alpha = 1.f;
-            } else if constexpr (ALPHA > 0) {
-                alpha = TConorm<(ALPHA > 0 ? ALPHA : 1)>::fold(alpha, q.frag, a.p.aggr_alpha_t_conorm_p);
-            } else {
-                alpha = tconorm_fold_rt(alpha_func, alpha, q.frag, a.p.aggr_alpha_t_conorm_p);
+            const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
+            if (!m) continue;
+            const int cnt = __popcll(m);
+            if (npairs + cnt > 64) run_batch();
+            if ((m >> lane) & 1ull) {
+                PairRec pr;
+                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2; pr.xp = t.xp; pr.yp = t.yp;
+                pr.code = (nfaces << 8) | lane; pr.pad0 = 0; pr.pad1 = 0;
+                s_pair[wave][npairs + __popcll(m & lt)] = pr;
             }
-
-            float wc[3];
-            const float zp = clip_and_depth(q, r, wc);
-            if (zp < a.p.near_ || zp > a.p.far_) continue;                       // :810
-#if GENDR_ABLATE == 3
-            alpha += zp;
-            continue;
-#endif
-
-            const long face_lin = (long)t.b * a.nf + fn;
-            const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
-            if (!rgb_soft) {                                                     // :815-822
-                if (zp < depth_min && inside_closed(q) && (a.p.double_side || front)) {
-                    depth_min = zp;
-                    face_min = fn;
-                    int own;
-                    sample_colour<TEXM>(col, own, wc, r, a, face_lin);
-                }
-            } else if (front || a.p.double_side) {                               // :824-838
-                const float zn = div_by(a.p.far_ - zp, a.r_zrange);
-                // exp_delta_zp and exp_z of :827-832: one of the two is exp(0) == 1 exactly
-                const bool deeper = zn > smax;
-                const float e = expf(div_by(deeper ? smax - zn : zn - smax, a.r_gamma));
-                const float edz = deeper ? e : 1.f;
-                const float ez = deeper ? 1.f : e;
-                if (deeper) smax = zn;
-                ssum = edz * ssum + ez * q.frag;
-                float cc[3]; int own;
-                sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
-#pragma unroll
-                for (int k = 0; k < 3; k++) col[k] = edz * col[k] + ez * q.frag * cc[k];
+            if (lane == 0) {
+                FaceEnt fe;
+                fe.fn = fn; fe.base = npairs; fe.mask = m;
+                s_face[wave][nfaces] = fe;
             }
+            npairs += cnt;
+            nfaces += 1;
         }
     }
+    if (npairs > 0) run_batch();
 
     if (!t.valid) return;
     // epilogue, kernel.cu:845-861
@@ -758,90 +865,85 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// wavefront sum with DPP adds; the total ends up in lane 63 (only lane 63 is meaningful)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    // quad swaps, half-row mirror, row mirror, then the two cross-row broadcasts of GFX9
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true));   // row_bcast:15 -> rows 1,3
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true));   // row_bcast:31 -> rows 2,3
-    return v;
-}
-
-// ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
 template <int TEXM> struct GradSlots { static constexpr int n = TEXM == kTexSurface1 ? 12 : (TEXM == kTexVertex ? 18 : 9); };
+
+struct PixIn {             // 48 bytes: per-pixel inputs of the backward pass, kernel.cu:916-917, :973, :980, :1013, :1021
+    float g[4], out[4], ssum, smax, pad0, pad1;
+};
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderArgs a)
 {
     constexpr int REC = record_floats(TEXM);
-    constexpr int NG = GradSlots<TEXM>::n;       // 9 vertex components, then texture components reduced per wave
+    constexpr int NG = GradSlots<TEXM>::n;       // 9 vertex components, then texture components summed per face in LDS
     constexpr int NT = NG > 9 ? NG - 9 : 1;
+    constexpr int WAVES = kThreads / 64;
+    __shared__ __attribute__((aligned(16))) PairRec s_pair[WAVES][64];
+    __shared__ __attribute__((aligned(16))) PixIn   s_pix[WAVES][64];
+    __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
+    __shared__ float s_acc[WAVES][64 * NG];
+
     TileCtx t;
     if (!tile_setup(t, a)) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const long P = (long)a.is * a.is;
     const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
-    const float gam = a.p.aggr_rgb_gamma;
 
-    // per-pixel inputs, kernel.cu:916-917, :973, :980, :1013, :1021
-    float g[4] = {0.f, 0.f, 0.f, 0.f}, out[4] = {0.f, 0.f, 0.f, 0.f}, ssum = 1.f, smax = 0.f;
-    if (t.valid) {
+    {
+        PixIn pi;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            g[k] = a.grad_rgba[((long)t.b * 4 + k) * P + t.pix];
-            out[k] = a.rgba[((long)t.b * 4 + k) * P + t.pix];
+        for (int k = 0; k < 4; k++) { pi.g[k] = 0.f; pi.out[k] = 0.f; }
+        pi.ssum = 1.f; pi.smax = 0.f; pi.pad0 = 0.f; pi.pad1 = 0.f;
+        if (t.valid) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                pi.g[k] = a.grad_rgba[((long)t.b * 4 + k) * P + t.pix];
+                pi.out[k] = a.rgba[((long)t.b * 4 + k) * P + t.pix];
+            }
+            pi.ssum = a.aux[((long)t.b * 2 + 0) * P + t.pix];
+            pi.smax = a.aux[((long)t.b * 2 + 1) * P + t.pix];
         }
-        ssum = a.aux[((long)t.b * 2 + 0) * P + t.pix];
-        smax = a.aux[((long)t.b * 2 + 1) * P + t.pix];
+        s_pix[wave][lane] = pi;
     }
 
-    const MaskPtr mrow = (MaskPtr)a.masks + (long)t.tile * a.chunks;
-    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
-    for (int c = 0; c < a.chunks; c++) {
-        unsigned long long w = mrow[c];
-        while (w) {
-            const int fn = c * 64 + __builtin_ctzll(w);
-            w &= w - 1;
-            const RecPtr rp = recs + (long)fn * REC;
+    const float* recs_g = a.records + (long)t.b * a.nf * REC;
+    int npairs = 0, nfaces = 0;
+
+    auto run_batch = [&]() {
+        for (int e = lane; e < nfaces * NG; e += 64) s_acc[wave][e] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < npairs) {
+            const PairRec pr = s_pair[wave][lane];
+            const int slot = pr.code >> 8;
+            const PixIn px = s_pix[wave][pr.code & 63];
+            const int fn = s_face[wave][slot].fn;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
-            load_record<0, kRecStage1>(r, rp);
-            bool live = t.valid && inside_box(r, t.xp, t.yp);
-            if (!__any(live)) continue;                      // whole wave outside the box: no further loads
+            gather_record<REC>(r, recs_g + (long)fn * REC);
             Pair q;
-            barycentrics(q, r, t.xp, t.yp);
-            live = live && !beyond_an_edge(q, r);
-            if (!__any(live)) continue;                      // whole wave beyond an edge by more than the cull radius
-            load_record<kRecStage1, kRecStage3>(r, rp);
-            live = live && soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
-            if (!__any(live)) continue;
-            load_record<kRecStage3, REC>(r, rp);
+            q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
 
             float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
-            float gt[NT];                      // texture partials reduced over the wave
+            float gt[NT];                      // texture partials
 #pragma unroll
             for (int k = 0; k < 9; k++) gv[k] = 0.f;
 #pragma unroll
             for (int k = 0; k < NT; k++) gt[k] = 0.f;
-
+            bool live = soft_fragment<DIST, SQ>(q, r, pr.xp, pr.yp, a, dp);
             if (live) {
                 // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
                 float C_xy = 0.f;
-                float C_alpha = g[3];
+                float C_alpha = px.g[3];
                 if (alpha_func != kAlphaHard) {
-                    if constexpr (ALPHA > 0) C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                    else                     C_alpha *= tconorm_grad_rt(alpha_func, out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    if constexpr (ALPHA > 0) C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    else                     C_alpha *= tconorm_grad_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
                 }
                 C_xy += C_alpha;
 
@@ -851,30 +953,30 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                 if (live) {
                     const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
                     if (!rgb_soft) {                                            // :997-1004
-                        if ((float)fn == smax) {
+                        if ((float)fn == px.smax) {
                             if constexpr (TEXM == kTexVertex) {
 #pragma unroll
                                 for (int k = 0; k < 3; k++)
 #pragma unroll
-                                    for (int j = 0; j < 3; j++) gt[3 * j + k] = wc[j] * g[k];
+                                    for (int j = 0; j < 3; j++) gt[3 * j + k] = wc[j] * px.g[k];
                             } else {
                                 float cc[3]; int own;
                                 sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
                                 if (own >= 0) {
                                     if constexpr (TEXM == kTexSurface1) {
 #pragma unroll
-                                        for (int k = 0; k < 3; k++) gt[k] = g[k];
+                                        for (int k = 0; k < 3; k++) gt[k] = px.g[k];
                                     } else {
 #pragma unroll
                                         for (int k = 0; k < 3; k++)
-                                            unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, g[k]);
+                                            unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, px.g[k]);
                                     }
                                 }
                             }
                         }
                     } else if (front || a.p.double_side) {                      // :1006-1030
                         const float zn = div_by(a.p.far_ - zp, a.r_zrange);
-                        const float zs = q.frag * expf(div_by(zn - smax, a.r_gamma)) / ssum;   // :1010
+                        const float zs = q.frag * expf(div_by(zn - px.smax, a.r_gamma)) / px.ssum;   // :1010
                         float cc[3]; int own;
                         sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
                         float C_rgb = 0.f;
@@ -882,13 +984,13 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                         for (int k = 0; k < 3; k++) {
                             if constexpr (TEXM == kTexVertex) {
 #pragma unroll
-                                for (int j = 0; j < 3; j++) gt[3 * j + k] = zs * (wc[j] * g[k]);
+                                for (int j = 0; j < 3; j++) gt[3 * j + k] = zs * (wc[j] * px.g[k]);
                             } else if constexpr (TEXM == kTexSurface1) {
-                                if (own >= 0) gt[k] = zs * g[k];
+                                if (own >= 0) gt[k] = zs * px.g[k];
                             } else {
-                                if (own >= 0) unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, zs * g[k]);
+                                if (own >= 0) unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, zs * px.g[k]);
                             }
-                            C_rgb += g[k] * (cc[k] - out[k]);                   // :1021
+                            C_rgb += px.g[k] * (cc[k] - px.out[k]);             // :1021
                         }
                         C_rgb *= zs;                                            // :1023
                         C_xy += C_rgb / q.frag;                                 // :1024
@@ -918,27 +1020,60 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                     }
                 }
             }
-            if (!__any(live)) continue;
-            if (!live) {
+            if (live) {
+                float* acc = &s_acc[wave][slot * NG];
 #pragma unroll
-                for (int k = 0; k < 9; k++) gv[k] = 0.f;
+                for (int k = 0; k < 9; k++)
+                    if (gv[k] != 0.f) atomicAdd(acc + k, gv[k]);
 #pragma unroll
-                for (int k = 0; k < NT; k++) gt[k] = 0.f;
-            }
-            // wavefront reduction: lane 63 ends up with every total and issues the atomics
-            // (one hardware fp32 atomic per (tile, face, component))
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const float s = wave_sum_to_lane63(gv[k]);
-                if (lane == 63 && s != 0.f) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, s);
-            }
-#pragma unroll
-            for (int k = 0; k < NG - 9; k++) {
-                const float s = wave_sum_to_lane63(gt[k]);
-                if (lane == 63 && s != 0.f) unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + k, s);
+                for (int k = 0; k < NG - 9; k++)
+                    if (gt[k] != 0.f) atomicAdd(acc + 9 + k, gt[k]);
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        // one hardware fp32 atomic per (batch, face, component)
+        for (int e = lane; e < nfaces * NG; e += 64) {
+            const float v = s_acc[wave][e];
+            if (v != 0.f) {
+                const int slot = e / NG, k = e - slot * NG;
+                const long face_lin = (long)t.b * a.nf + s_face[wave][slot].fn;
+                if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
+                else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        npairs = 0;
+        nfaces = 0;
+    };
+
+    const MaskPtr mrow = (MaskPtr)a.masks + (long)t.tile * a.chunks;
+    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
+    for (int c = 0; c < a.chunks; c++) {
+        unsigned long long w = mrow[c];
+        while (w) {
+            const int fn = c * 64 + __builtin_ctzll(w);
+            w &= w - 1;
+            Pair q;
+            const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
+            if (!m) continue;
+            const int cnt = __popcll(m);
+            if (npairs + cnt > 64) run_batch();
+            if ((m >> lane) & 1ull) {
+                PairRec pr;
+                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2; pr.xp = t.xp; pr.yp = t.yp;
+                pr.code = (nfaces << 8) | lane; pr.pad0 = 0; pr.pad1 = 0;
+                s_pair[wave][npairs + __popcll(m & lt)] = pr;
+            }
+            if (lane == 0) {
+                FaceEnt fe;
+                fe.fn = fn; fe.base = npairs; fe.mask = m;
+                s_face[wave][nfaces] = fe;
+            }
+            npairs += cnt;
+            nfaces += 1;
+        }
     }
+    if (npairs > 0) run_batch();
 }
 
 }  // namespace gendr
