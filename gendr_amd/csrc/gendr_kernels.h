@@ -669,17 +669,21 @@ constexpr int kFlagContrib = 1;   // passed :769 and :784 -> folds into alpha
 constexpr int kFlagDepthOk = 2;   // near <= zp <= far (:810)
 constexpr int kFlagRgb     = 4;   // eligible for the RGB aggregation (:816 resp. :825)
 
-// per-lane copy of the record fields phase B needs (stage 2 and 3 plus the flag word), 16-byte vector loads
-template <int REC>
+// per-lane copy of record floats [4*Q0, 4*Q1) with 16-byte vector loads (phase B: lane = pair)
+template <int Q0, int Q1>
 __device__ __forceinline__ void gather_record(float* r, const float* __restrict__ rec)
 {
     const float4* src = reinterpret_cast<const float4*>(rec);
 #pragma unroll
-    for (int q = 3; q < REC / 4; q++) {             // floats [12, REC): bits live in [13]
+    for (int q = Q0; q < Q1; q++) {
         const float4 v = src[q];
         r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
 }
+// the distance stage needs floats [20, 42) (+ the flag word at 13 for the obtuse-corner bits);
+// depth / colour need [42, REC)
+constexpr int kGatherA0 = 5, kGatherA1 = 11;     // floats [20, 44)
+constexpr int kGatherB0 = 10;                    // floats [40, REC)
 
 // phase A for one listed face; returns the ballot of surviving lanes (0 = nothing to do)
 template <int REC>
@@ -747,12 +751,15 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
             const int fn = s_face[wave][pr.code >> 8].fn;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
-            gather_record<REC>(r, recs_g + (long)fn * REC);
+            const float* rg = recs_g + (long)fn * REC;
+            r[kRecBits] = rg[kRecBits];
+            gather_record<kGatherA0, kGatherA1>(r, rg);
             Pair q;
             q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
             FwdRes res;
             res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.pad0 = res.pad1 = 0;
             if (soft_fragment<DIST, SQ>(q, r, pr.xp, pr.yp, a, dp)) {
+                gather_record<kGatherB0, REC / 4>(r, rg);
                 res.flags = kFlagContrib;
                 res.frag = q.frag;
                 float wc[3];
@@ -883,7 +890,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
     __shared__ __attribute__((aligned(16))) PairRec s_pair[WAVES][64];
     __shared__ __attribute__((aligned(16))) PixIn   s_pix[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
-    __shared__ float s_acc[WAVES][64 * NG];
+    __shared__ float s_val[WAVES][NG * 65];      // per-pair gradient partials, component-major, rows padded to 65
 
     TileCtx t;
     if (!tile_setup(t, a)) return;
@@ -917,7 +924,6 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
     int npairs = 0, nfaces = 0;
 
     auto run_batch = [&]() {
-        for (int e = lane; e < nfaces * NG; e += 64) s_acc[wave][e] = 0.f;
         __builtin_amdgcn_wave_barrier();
         if (lane < npairs) {
             const PairRec pr = s_pair[wave][lane];
@@ -926,7 +932,9 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             const int fn = s_face[wave][slot].fn;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
-            gather_record<REC>(r, recs_g + (long)fn * REC);
+            const float* rg = recs_g + (long)fn * REC;
+            r[kRecBits] = rg[kRecBits];
+            gather_record<kGatherA0, kGatherA1>(r, rg);
             Pair q;
             q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
 
@@ -938,6 +946,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             for (int k = 0; k < NT; k++) gt[k] = 0.f;
             bool live = soft_fragment<DIST, SQ>(q, r, pr.xp, pr.yp, a, dp);
             if (live) {
+                gather_record<kGatherB0, REC / 4>(r, rg);
                 // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
                 float C_xy = 0.f;
                 float C_alpha = px.g[3];
@@ -1020,23 +1029,24 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                     }
                 }
             }
-            if (live) {
-                float* acc = &s_acc[wave][slot * NG];
+            // every pair lane publishes its partials (zeros if the pair dropped out): column = pair index
 #pragma unroll
-                for (int k = 0; k < 9; k++)
-                    if (gv[k] != 0.f) atomicAdd(acc + k, gv[k]);
+            for (int k = 0; k < 9; k++) s_val[wave][k * 65 + lane] = live ? gv[k] : 0.f;
 #pragma unroll
-                for (int k = 0; k < NG - 9; k++)
-                    if (gt[k] != 0.f) atomicAdd(acc + 9 + k, gt[k]);
-            }
+            for (int k = 0; k < NG - 9; k++) s_val[wave][(9 + k) * 65 + lane] = live ? gt[k] : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
-        // one hardware fp32 atomic per (batch, face, component)
+        // The pairs of one face are contiguous.  One lane per (face, component) sums its segment in pair order and
+        // issues one hardware fp32 atomic: deterministic inside the batch, no LDS atomics.
         for (int e = lane; e < nfaces * NG; e += 64) {
-            const float v = s_acc[wave][e];
+            const int slot = e / NG, k = e - slot * NG;
+            const FaceEnt fe = s_face[wave][slot];
+            const int cnt = __popcll(fe.mask);
+            const float* col = &s_val[wave][k * 65 + fe.base];
+            float v = 0.f;
+            for (int i = 0; i < cnt; i++) v += col[i];
             if (v != 0.f) {
-                const int slot = e / NG, k = e - slot * NG;
-                const long face_lin = (long)t.b * a.nf + s_face[wave][slot].fn;
+                const long face_lin = (long)t.b * a.nf + fe.fn;
                 if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
                 else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
             }
