@@ -328,10 +328,11 @@ __global__ __launch_bounds__(kThreads) void face_info_kernel(const float* __rest
 // pixel / tile geometry
 // ---------------------------------------------------------------------------------------------
 // (2.*idx + 1. - is) / is of kernel.cu:718-719.  The reference evaluates it in double and rounds to float;
-// numerator and denominator are integers below 2^24, so the float division rounds to the same value.
+// numerator and denominator are integers below 2^24, so the float division rounds to the same value
+// (and div_by() reproduces that float division exactly).
 __device__ __forceinline__ float pixel_coord(int idx, int is)
 {
-    return (float)(2 * idx + 1 - is) / (float)is;
+    return div_by((float)(2 * idx + 1 - is), 1. / (double)is);   // 1/is folds to a wave-uniform constant
 }
 
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8).  Remap so that each XCD walks a
@@ -414,6 +415,15 @@ struct TileCtx {
     float xp, yp;       // pixel centre, kernel.cu:716-719
     long  pix;          // row * is + xi
 };
+
+// pixel centre of lane `pl` of the tile whose lane `lane` is this thread (same arithmetic as tile_setup)
+__device__ __forceinline__ void pair_pixel(float& xp, float& yp, const TileCtx& t, int pl, int is)
+{
+    const int lane = threadIdx.x & 63;
+    const int xi = t.xi - (lane & 7) + (pl & 7), row = t.row - (lane >> 3) + (pl >> 3);
+    xp = pixel_coord(xi, is);
+    yp = pixel_coord(is - 1 - row, is);
+}
 
 __device__ __forceinline__ bool tile_setup(TileCtx& t, const RenderArgs& a)
 {
@@ -654,10 +664,14 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 //                      CU as one hardware fp32 atomic per (tile batch, face, component).
 // Everything is wavefront-local: no barriers.
 // ---------------------------------------------------------------------------------------------
-struct PairRec {           // 32 bytes
+struct PairRec {           // 16 bytes
     float w0, w1, w2;      // barycentrics of the pixel w.r.t. the face (:39-43)
-    float xp, yp;          // pixel centre
     int   code;            // (face slot in the batch << 8) | pixel lane
+};
+struct PairRecXY {         // 32 bytes: forward keeps the pixel centre with the pair (its LDS budget allows it,
+    float w0, w1, w2;      // and recomputing it costs the forward kernel an occupancy step in registers)
+    int   code;
+    float xp, yp;
     int   pad0, pad1;
 };
 struct FaceEnt {           // 16 bytes
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int WAVES = kThreads / 64;
-    __shared__ __attribute__((aligned(16))) PairRec s_pair[WAVES][64];
+    __shared__ __attribute__((aligned(16))) PairRecXY s_pair[WAVES][64];
     __shared__ __attribute__((aligned(16))) FwdRes  s_res[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
 
@@ -747,7 +761,7 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
         __builtin_amdgcn_wave_barrier();
         // ---- phase B: one pair per lane
         if (lane < npairs) {
-            const PairRec pr = s_pair[wave][lane];
+            const PairRecXY pr = s_pair[wave][lane];
             const int fn = s_face[wave][pr.code >> 8].fn;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
@@ -756,9 +770,10 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
             gather_record<kGatherA0, kGatherA1>(r, rg);
             Pair q;
             q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
+            const float pxp = pr.xp, pyp = pr.yp;
             FwdRes res;
             res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.pad0 = res.pad1 = 0;
-            if (soft_fragment<DIST, SQ>(q, r, pr.xp, pr.yp, a, dp)) {
+            if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) {
                 gather_record<kGatherB0, REC / 4>(r, rg);
                 res.flags = kFlagContrib;
                 res.frag = q.frag;
@@ -837,9 +852,9 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
             const int cnt = __popcll(m);
             if (npairs + cnt > 64) run_batch();
             if ((m >> lane) & 1ull) {
-                PairRec pr;
-                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2; pr.xp = t.xp; pr.yp = t.yp;
-                pr.code = (nfaces << 8) | lane; pr.pad0 = 0; pr.pad1 = 0;
+                PairRecXY pr;
+                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
+                pr.code = (nfaces << 8) | lane; pr.xp = t.xp; pr.yp = t.yp; pr.pad0 = 0; pr.pad1 = 0;
                 s_pair[wave][npairs + __popcll(m & lt)] = pr;
             }
             if (lane == 0) {
@@ -876,8 +891,8 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
 // ---------------------------------------------------------------------------------------------
 template <int TEXM> struct GradSlots { static constexpr int n = TEXM == kTexSurface1 ? 12 : (TEXM == kTexVertex ? 18 : 9); };
 
-struct PixIn {             // 48 bytes: per-pixel inputs of the backward pass, kernel.cu:916-917, :973, :980, :1013, :1021
-    float g[4], out[4], ssum, smax, pad0, pad1;
+struct PixIn {             // 40 bytes: per-pixel inputs of the backward pass, kernel.cu:916-917, :973, :980, :1013, :1021
+    float g[4], out[4], ssum, smax;
 };
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
@@ -907,7 +922,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
         PixIn pi;
 #pragma unroll
         for (int k = 0; k < 4; k++) { pi.g[k] = 0.f; pi.out[k] = 0.f; }
-        pi.ssum = 1.f; pi.smax = 0.f; pi.pad0 = 0.f; pi.pad1 = 0.f;
+        pi.ssum = 1.f; pi.smax = 0.f;
         if (t.valid) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -937,6 +952,8 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             gather_record<kGatherA0, kGatherA1>(r, rg);
             Pair q;
             q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
+            float pxp, pyp;
+            pair_pixel(pxp, pyp, t, pr.code & 63, a.is);
 
             float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
             float gt[NT];                      // texture partials
@@ -944,7 +961,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             for (int k = 0; k < 9; k++) gv[k] = 0.f;
 #pragma unroll
             for (int k = 0; k < NT; k++) gt[k] = 0.f;
-            bool live = soft_fragment<DIST, SQ>(q, r, pr.xp, pr.yp, a, dp);
+            bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp);
             if (live) {
                 gather_record<kGatherB0, REC / 4>(r, rg);
                 // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
@@ -1070,8 +1087,8 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             if (npairs + cnt > 64) run_batch();
             if ((m >> lane) & 1ull) {
                 PairRec pr;
-                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2; pr.xp = t.xp; pr.yp = t.yp;
-                pr.code = (nfaces << 8) | lane; pr.pad0 = 0; pr.pad1 = 0;
+                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
+                pr.code = (nfaces << 8) | lane;
                 s_pair[wave][npairs + __popcll(m & lt)] = pr;
             }
             if (lane == 0) {
