@@ -712,6 +712,34 @@ __device__ __forceinline__ unsigned long long collect_pairs(const TileCtx& t, Re
     return __ballot(live);
 }
 
+// Walks the faces listed in a tile's mask row in ascending order and calls body(fn, rp) with the face's
+// (wave-uniform) record pointer.  Lane l loads mask word l -- one coalesced load instead of a chain of
+// dependent scalar loads; most words are zero, so a ballot picks the non-zero words and v_readlane hands
+// each of them to the scalar bit scan.
+template <int REC, typename Body>
+__device__ __forceinline__ void for_each_listed_face(const RenderArgs& a, const TileCtx& t, Body body)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long* mrow = a.masks + (long)t.tile * a.chunks;
+    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
+    for (int word0 = 0; word0 < a.chunks; word0 += 64) {
+        const int nwords = min(64, a.chunks - word0);
+        const unsigned long long wv = lane < nwords ? mrow[word0 + lane] : 0ull;
+        unsigned long long nz = __ballot(wv != 0ull);
+        while (nz) {
+            const int j = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), j) << 32)
+                                 | (unsigned)__builtin_amdgcn_readlane((int)wv, j);
+            while (w) {
+                const int fn = (word0 + j) * 64 + __builtin_ctzll(w);
+                w &= w - 1;
+                body(fn, recs + (long)fn * REC);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -839,33 +867,26 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
         nfaces = 0;
     };
 
-    const MaskPtr mrow = (MaskPtr)a.masks + (long)t.tile * a.chunks;
-    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
-    for (int c = 0; c < a.chunks; c++) {
-        unsigned long long w = mrow[c];
-        while (w) {
-            const int fn = c * 64 + __builtin_ctzll(w);
-            w &= w - 1;
-            Pair q;
-            const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
-            if (!m) continue;
-            const int cnt = __popcll(m);
-            if (npairs + cnt > 64) run_batch();
-            if ((m >> lane) & 1ull) {
-                PairRecXY pr;
-                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
-                pr.code = (nfaces << 8) | lane; pr.xp = t.xp; pr.yp = t.yp; pr.pad0 = 0; pr.pad1 = 0;
-                s_pair[wave][npairs + __popcll(m & lt)] = pr;
-            }
-            if (lane == 0) {
-                FaceEnt fe;
-                fe.fn = fn; fe.base = npairs; fe.mask = m;
-                s_face[wave][nfaces] = fe;
-            }
-            npairs += cnt;
-            nfaces += 1;
+    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) {
+        Pair q;
+        const unsigned long long m = collect_pairs<REC>(t, rp, q);
+        if (!m) return;
+        const int cnt = __popcll(m);
+        if (npairs + cnt > 64) run_batch();
+        if ((m >> lane) & 1ull) {
+            PairRecXY pr;
+            pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
+            pr.code = (nfaces << 8) | lane; pr.xp = t.xp; pr.yp = t.yp; pr.pad0 = 0; pr.pad1 = 0;
+            s_pair[wave][npairs + __popcll(m & lt)] = pr;
         }
-    }
+        if (lane == 0) {
+            FaceEnt fe;
+            fe.fn = fn; fe.base = npairs; fe.mask = m;
+            s_face[wave][nfaces] = fe;
+        }
+        npairs += cnt;
+        nfaces += 1;
+    });
     if (npairs > 0) run_batch();
 
     if (!t.valid) return;
@@ -1073,33 +1094,26 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
         nfaces = 0;
     };
 
-    const MaskPtr mrow = (MaskPtr)a.masks + (long)t.tile * a.chunks;
-    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
-    for (int c = 0; c < a.chunks; c++) {
-        unsigned long long w = mrow[c];
-        while (w) {
-            const int fn = c * 64 + __builtin_ctzll(w);
-            w &= w - 1;
-            Pair q;
-            const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
-            if (!m) continue;
-            const int cnt = __popcll(m);
-            if (npairs + cnt > 64) run_batch();
-            if ((m >> lane) & 1ull) {
-                PairRec pr;
-                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
-                pr.code = (nfaces << 8) | lane;
-                s_pair[wave][npairs + __popcll(m & lt)] = pr;
-            }
-            if (lane == 0) {
-                FaceEnt fe;
-                fe.fn = fn; fe.base = npairs; fe.mask = m;
-                s_face[wave][nfaces] = fe;
-            }
-            npairs += cnt;
-            nfaces += 1;
+    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) {
+        Pair q;
+        const unsigned long long m = collect_pairs<REC>(t, rp, q);
+        if (!m) return;
+        const int cnt = __popcll(m);
+        if (npairs + cnt > 64) run_batch();
+        if ((m >> lane) & 1ull) {
+            PairRec pr;
+            pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
+            pr.code = (nfaces << 8) | lane;
+            s_pair[wave][npairs + __popcll(m & lt)] = pr;
         }
-    }
+        if (lane == 0) {
+            FaceEnt fe;
+            fe.fn = fn; fe.base = npairs; fe.mask = m;
+            s_face[wave][nfaces] = fe;
+        }
+        npairs += cnt;
+        nfaces += 1;
+    });
     if (npairs > 0) run_batch();
 }
 
