@@ -354,9 +354,9 @@ __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry
 // ---------------------------------------------------------------------------------------------
 // binning: masks[b][tile][chunk], bit f of chunk c = face 64c+f of image b may touch the 8x8 tile.
 // One wavefront takes 64 faces (lane = face, coalesced box load) and a block of 8x8 tiles (a 64x64 pixel
-// super-tile): for every tile of the block the ballot of "box meets tile" IS the mask word; lane t keeps the
-// word of tile t and the 64 words leave in one store.  A chunk whose union box misses the super-tile writes
-// zeros without looping.
+// super-tile, lane = tile as well).  A ballot finds the few faces whose box meets the super-tile at all; for
+// each of them the box is broadcast with v_readlane and every tile lane sets its bit.  Lane t ends up with the
+// mask word of tile t and the 64 words leave in one store.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void bin_faces_kernel(
     const float* __restrict__ boxes, unsigned long long* __restrict__ masks,
@@ -376,29 +376,26 @@ __global__ __launch_bounds__(kThreads) void bin_faces_kernel(
     float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
     if (have) box = reinterpret_cast<const float4*>(boxes)[(long)b * nf + fi];
 
-    // lane t owns tile t of the super-tile: its rectangle (computed once) and, at the end, its mask word
+    // lane t also owns tile t of the super-tile: its rectangle and, at the end, its mask word
     const int ty_l = sy * 8 + (lane >> 3), tx_l = sx * 8 + (lane & 7);
     const bool tile_ok = ty_l < tiles_x && tx_l < tiles_x;
-    const float rx_lo_l = pixel_coord(tx_l * 8, is), rx_hi_l = pixel_coord(min(tx_l * 8 + 7, is - 1), is);
-    const float ry_hi_l = pixel_coord(is - 1 - ty_l * 8, is), ry_lo_l = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is);
+    const float rx_lo = pixel_coord(tx_l * 8, is), rx_hi = pixel_coord(min(tx_l * 8 + 7, is - 1), is);
+    const float ry_hi = pixel_coord(is - 1 - ty_l * 8, is), ry_lo = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is);
     unsigned long long mine = 0ull;
 
-    // union of the chunk's boxes against the super-tile rectangle
+    // faces of the chunk whose box meets the super-tile at all (usually a handful of the 64)
     const float sx_lo = pixel_coord(sx * 64, is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is);
     const float sy_hi = pixel_coord(is - 1 - sy * 64, is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is);
-    const bool any_hit = cull ? __any(have && rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box)) : true;
-    if (any_hit) {
-        const unsigned long long ok_tiles = __ballot(tile_ok);
-        for (int t = 0; t < 64; t++) {
-            if (!((ok_tiles >> t) & 1ull)) continue;                         // uniform
-            const float rx_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_lo_l), t));
-            const float rx_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_hi_l), t));
-            const float ry_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_lo_l), t));
-            const float ry_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_hi_l), t));
-            const bool hit = have && (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, box) : true);
-            const unsigned long long m = __ballot(hit);
-            if (lane == t) mine = m;
-        }
+    unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
+    while (cand) {
+        const int f = __builtin_ctzll(cand);
+        cand &= cand - 1;
+        float4 fb;                                                       // face f's box, broadcast to every tile lane
+        fb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.x), f));
+        fb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.y), f));
+        fb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.z), f));
+        fb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.w), f));
+        if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << f;
     }
     if (tile_ok)
         masks[((long)b * tiles_x * tiles_x + (long)ty_l * tiles_x + tx_l) * chunks + c] = mine;
