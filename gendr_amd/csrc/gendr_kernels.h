@@ -1050,15 +1050,30 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                         if constexpr (DIST >= 0) C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
                         else                     C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
                         const float tw[3] = {q.t0 + q.w0, q.t1 + q.w1, q.t2 + q.w2};
+                        if (squared) {
 #pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            if (squared) {
+                            for (int k = 0; k < 3; k++) {
                                 gv[3 * k + 0] = 2 * q.sign * C_xy * tw[k] * q.dx;
                                 gv[3 * k + 1] = 2 * q.sign * C_xy * tw[k] * q.dy;
+                            }
+                        } else {
+                            // (double)num / max(sqrt(dx^2+dy^2), 1e-6), rounded to float (:1049).  When the divisor is
+                            // the float square root, one double reciprocal serves all six quotients exactly (div_by);
+                            // below 1e-6 the divisor is the double literal and the true divisions are kept.
+                            const float len = sqrtf(q.dx * q.dx + q.dy * q.dy);
+                            if ((double)len >= 1e-6) {
+                                const double rlen = 1. / (double)len;
+#pragma unroll
+                                for (int k = 0; k < 3; k++) {
+                                    gv[3 * k + 0] = div_by(q.sign * C_xy * tw[k] * q.dx, rlen);
+                                    gv[3 * k + 1] = div_by(q.sign * C_xy * tw[k] * q.dy, rlen);
+                                }
                             } else {
-                                const double nrm = fmax((double)sqrtf(q.dx * q.dx + q.dy * q.dy), 1e-6);
-                                gv[3 * k + 0] = (float)((double)(q.sign * C_xy * tw[k] * q.dx) / nrm);
-                                gv[3 * k + 1] = (float)((double)(q.sign * C_xy * tw[k] * q.dy) / nrm);
+#pragma unroll
+                                for (int k = 0; k < 3; k++) {
+                                    gv[3 * k + 0] = (float)((double)(q.sign * C_xy * tw[k] * q.dx) / 1e-6);
+                                    gv[3 * k + 1] = (float)((double)(q.sign * C_xy * tw[k] * q.dy) / 1e-6);
+                                }
                             }
                         }
                     }
