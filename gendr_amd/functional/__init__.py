@@ -1,1 +1,5 @@
 from .renderer import render, soft_rasterize, GenDRFunction
+from .geometry import (look_at, look, perspective, orthogonal, face_vertices, vertex_normals,
+                       get_points_from_angles)
+from .lighting import ambient_lighting, directional_lighting
+from .obj_io import load_obj, save_obj, save_voxel, voxelization

@@ -128,3 +128,36 @@ def test_forward_is_deterministic_and_batch_items_independent(native_lib):
     assert torch.equal(a, b)
     one = render(fv[2:3], tex[2:3], image_size=48)
     assert torch.equal(a[2:3, 3], one[:, 3])               # RGB can differ through the texel-overflow quirk
+
+
+def test_shape_optimisation_loop_through_the_alias_package(native_lib):
+    """The call pattern of experiments/opt_shape.py:259-311: Mesh -> Lighting -> LookAt -> GenDR (soft, hard RGB),
+    IoU loss on alpha, Adam step; plus the script's hard renderer under no_grad (opt_shape.py:148-159)."""
+    import gendr
+    from gendr_amd.synthetic import icosphere
+    v, f = icosphere(2)
+    target = gendr.Mesh(torch.from_numpy(v * 0.9).cuda()[None].repeat(4, 1, 1), torch.from_numpy(f).int().cuda()[None].repeat(4, 1, 1))
+    verts = torch.nn.Parameter(torch.from_numpy(v * 0.6).cuda())
+    faces = torch.from_numpy(f).int().cuda()
+    cam = gendr.LookAt(viewing_angle=15)
+    cam.set_eyes_from_angles(torch.full((4,), 2.732), torch.full((4,), 30.0), torch.tensor([0.0, 90.0, 180.0, 270.0]))
+    lights = gendr.Lighting()
+    soft = gendr.GenDR(image_size=64, dist_func='uniform', dist_scale=None, dist_eps=1e4, aggr_alpha_func='probabilistic',
+                       aggr_rgb_func='hard')
+    soft.dist_scale = np.float64(10 ** -1.5)                # set by attribute, numpy scalar (opt_shape.py:289,327)
+    hard = gendr.GenDR(image_size=64, dist_func=0, dist_scale=0.0, aggr_alpha_func=0, aggr_rgb_func='hard')
+    with torch.no_grad():
+        ref = hard(cam(lights(target)))[:, 3]
+    assert set(ref.unique().tolist()) <= {0.0, 1.0}
+    opt = torch.optim.Adam([verts], lr=0.02)
+    first = None
+    for _ in range(15):
+        mesh = gendr.Mesh(verts[None].repeat(4, 1, 1), faces[None].repeat(4, 1, 1))
+        pred = soft(cam(lights(mesh)))[:, 3]
+        iou = (pred * ref).sum((1, 2)) / ((pred + ref - pred * ref).sum((1, 2)) + 1e-6)
+        loss = (1 - iou).mean()
+        first = loss.item() if first is None else first
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    assert torch.isfinite(verts).all() and loss.item() < first
