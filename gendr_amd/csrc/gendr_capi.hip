@@ -46,6 +46,13 @@ const KernelEntry kGeneric[3] = {
     { {-1, -1, -1, -1, kTexSurfaceN}, render_forward_kernel<-1, -1, -1, -1, kTexSurfaceN>, render_backward_kernel<-1, -1, -1, -1, kTexSurfaceN> },
 };
 
+// light runtime-dispatch kernels: 13 light distributions x 5 light alpha aggregators, any RGB / squared flag
+const KernelEntry kGenericLight[3] = {
+    { {-2, -2, -1, -1, kTexSurface1}, render_forward_kernel<-2, -2, -1, -1, kTexSurface1>, render_backward_kernel<-2, -2, -1, -1, kTexSurface1> },
+    { {-2, -2, -1, -1, kTexVertex},   render_forward_kernel<-2, -2, -1, -1, kTexVertex>,   render_backward_kernel<-2, -2, -1, -1, kTexVertex> },
+    { {-2, -2, -1, -1, kTexSurfaceN}, render_forward_kernel<-2, -2, -1, -1, kTexSurfaceN>, render_backward_kernel<-2, -2, -1, -1, kTexSurfaceN> },
+};
+
 const KernelEntry& pick_kernel(const gendr_params* p, int texm)
 {
     for (const KernelEntry& e : kSpecialised) {
@@ -53,6 +60,7 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm)
             e.key.sq == (p->dist_squared ? 1 : 0) && e.key.texm == texm)
             return e;
     }
+    if (is_light_dist(p->dist_func) && is_light_alpha(p->aggr_alpha_func)) return kGenericLight[texm];
     return kGeneric[texm];
 }
 

@@ -566,8 +566,9 @@ __device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp,
         const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
         if (!squared) dis = sqrtf(dis);                                             // :770-772
         q.dis = dis;
-        if constexpr (DIST >= 0) q.frag = Dist<(DIST >= 0 ? DIST : 0)>::cdf(q.sign, dis, dp);
-        else                     q.frag = cdf_rt(dist, q.sign, dis, dp);
+        if constexpr (DIST >= 0)       q.frag = Dist<(DIST >= 0 ? DIST : 0)>::cdf(q.sign, dis, dp);
+        else if constexpr (DIST == -2) q.frag = cdf_light_rt(dist, q.sign, dis, dp);
+        else                           q.frag = cdf_rt(dist, q.sign, dis, dp);
     }
     return !((double)q.frag <= kProbThreshold);                                     // :784
 }
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
     int npairs = 0, nfaces = 0;
 
-    auto run_batch = [&]() {
+    auto run_batch = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
         // ---- phase B: one pair per lane
         if (lane < npairs) {
@@ -836,6 +837,8 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
                 if ((double)res.frag > 0.5) alpha = 1.f;
             } else if constexpr (ALPHA > 0) {
                 alpha = TConorm<(ALPHA > 0 ? ALPHA : 1)>::fold(alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
+            } else if constexpr (ALPHA == -2) {
+                alpha = tconorm_fold_light_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
             } else {
                 alpha = tconorm_fold_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
             }
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
         nfaces = 0;
     };
 
-    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) {
+    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
         Pair q;
         const unsigned long long m = collect_pairs<REC>(t, rp, q);
         if (!m) return;
@@ -956,7 +959,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
     int npairs = 0, nfaces = 0;
 
-    auto run_batch = [&]() {
+    auto run_batch = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
         if (lane < npairs) {
             const PairRec pr = s_pair[wave][lane];
@@ -986,8 +989,9 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                 float C_xy = 0.f;
                 float C_alpha = px.g[3];
                 if (alpha_func != kAlphaHard) {
-                    if constexpr (ALPHA > 0) C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                    else                     C_alpha *= tconorm_grad_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    if constexpr (ALPHA > 0)        C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    else if constexpr (ALPHA == -2) C_alpha *= tconorm_grad_light_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    else                            C_alpha *= tconorm_grad_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
                 }
                 C_xy += C_alpha;
 
@@ -1047,8 +1051,9 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                     // distance gradient, kernel.cu:1034-1052.  Heaviside: D' = 0 times uninitialised
                     // values in the reference -> defined as exactly 0 here (DESIGN.md quirk i).
                     if (dist != kHeaviside) {
-                        if constexpr (DIST >= 0) C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
-                        else                     C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
+                        if constexpr (DIST >= 0)       C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
+                        else if constexpr (DIST == -2) C_xy *= pdf_light_rt(dist, q.sign, q.dis, dp);
+                        else                           C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
                         const float tw[3] = {q.t0 + q.w0, q.t1 + q.w1, q.t2 + q.w2};
                         if (squared) {
 #pragma unroll
@@ -1106,7 +1111,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
         nfaces = 0;
     };
 
-    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) {
+    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
         Pair q;
         const unsigned long long m = collect_pairs<REC>(t, rp, q);
         if (!m) return;

@@ -286,6 +286,32 @@ GENDR_HD float pdf_rt(int id, float sign, float x, const DistParams& d)
     }
 }
 
+// "Light" distributions: everything except the ones whose device code needs long double-precision libm
+// expansions (gudermannian: tanh/atan in double; gamma: tgamma + 32-term series + pow; levy: erfc/exp/pow in
+// double).  Runtime-dispatch kernels exist in a light and a full flavour so that the heavy branches do not
+// dictate the register allocation (hence the occupancy) of every non-specialised option set.
+#define GENDR_FOR_EACH_LIGHT_DIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(9) X(10) X(11) X(12) X(13)
+GENDR_HD bool is_light_dist(int id) { return id >= 0 && id <= 13 && id != 7; }
+
+GENDR_HD float cdf_light_rt(int id, float sign, float x, const DistParams& d)
+{
+    switch (id) {
+#define X(i) case i: return Dist<i>::cdf(sign, x, d);
+        GENDR_FOR_EACH_LIGHT_DIST(X)
+#undef X
+        default: return quiet_nan();
+    }
+}
+GENDR_HD float pdf_light_rt(int id, float sign, float x, const DistParams& d)
+{
+    switch (id) {
+#define X(i) case i: return Dist<i>::pdf(sign, x, d);
+        GENDR_FOR_EACH_LIGHT_DIST(X)
+#undef X
+        default: return quiet_nan();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // t-conorms.  fold(a, b, p): alpha <- T(alpha, D_f) (kernel.cu:474-563);
 // grad(A, b, p): d alpha_final / d D_f from the final alpha A (kernel.cu:567-614).
@@ -406,6 +432,29 @@ GENDR_HD float tconorm_grad_rt(int id, float A, float b, float p)
 #define X(i) case i: return TConorm<i>::grad(A, b, p);
         GENDR_FOR_EACH_TCONORM(X)
 #undef X
+        default: return quiet_nan();
+    }
+}
+
+// light t-conorms: max, probabilistic, einstein, hamacher (no pow / log)
+GENDR_HD bool is_light_alpha(int id) { return id >= 0 && id <= 4; }
+GENDR_HD float tconorm_fold_light_rt(int id, float a, float b, float p)
+{
+    switch (id) {
+        case 1: return TConorm<1>::fold(a, b, p);
+        case 2: return TConorm<2>::fold(a, b, p);
+        case 3: return TConorm<3>::fold(a, b, p);
+        case 4: return TConorm<4>::fold(a, b, p);
+        default: return quiet_nan();
+    }
+}
+GENDR_HD float tconorm_grad_light_rt(int id, float A, float b, float p)
+{
+    switch (id) {
+        case 1: return TConorm<1>::grad(A, b, p);
+        case 2: return TConorm<2>::grad(A, b, p);
+        case 3: return TConorm<3>::grad(A, b, p);
+        case 4: return TConorm<4>::grad(A, b, p);
         default: return quiet_nan();
     }
 }
