@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
                             // (double)num / max(sqrt(dx^2+dy^2), 1e-6), rounded to float (:1049).  When the divisor is
                             // the float square root, one double reciprocal serves all six quotients exactly (div_by);
                             // below 1e-6 the divisor is the double literal and the true divisions are kept.
-                            const float len = sqrtf(q.dx * q.dx + q.dy * q.dy);
+                            const float len = q.dis;   // == sqrtf(dx*dx + dy*dy): the very value soft_fragment() computed (:771)
                             if ((double)len >= 1e-6) {
                                 const double rlen = 1. / (double)len;
 #pragma unroll
