@@ -78,6 +78,24 @@ def cpu_baseline(cfg, fv, tex, target_seconds=15.0):
                        % (n, isz, isz, fvn.shape[1], cores, tn))
 
 
+def cpu_baseline_torch(cfg, fv, tex):
+    """The pure-PyTorch evaluation of the same per-pixel math (oracle/torch_ref.py) on one frame, all host threads;
+    BASELINE.json's north_star asks for this number next to the GPU one.  Only for option sets it covers."""
+    from oracle import torch_ref
+    opts = dict(cfg['opts'])
+    opts.setdefault('double_side', False)
+    if opts.get('dist_func') not in torch_ref.DIST or opts.get('aggr_alpha_func') not in torch_ref.ALPHA or 'dist_shape' in opts:
+        return None
+    torch.set_num_threads(os.cpu_count() or 1)
+    isz = cfg['image_size']
+    g = torch.randn(1, 4, isz, isz, generator=torch.Generator().manual_seed(1))
+    t0 = time.perf_counter()
+    torch_ref.render(fv[:1].cpu(), tex[:1].cpu(), isz, grad=g, **opts)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample='1 frame of the same workload, forward+backward, vectorised pure PyTorch (oracle/torch_ref.py), %.1f s' % dt)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -198,6 +216,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, fv_all[:B], tex_all[:B])
+            tb = cpu_baseline_torch(cfg, fv_all[:B], tex_all[:B])
+            if tb is not None:
+                out['cpu_baseline_torch'] = tb
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -12,8 +12,8 @@
  * restatement of that kernel's published arithmetic, written from the source
  * text, citing the lines it follows ("kernel.cu:N").  What pins it instead is
  * listed in DESIGN.md (closed-form CDF/pdf checks against scipy, finite
- * differences of the fp64 build, a second independent restatement in
- * PyTorch).
+* differences of the fp64 build, a second independent restatement in
+ * PyTorch: oracle/torch_ref.py).
  *
  * Two instantiations exist, mirroring AT_DISPATCH_FLOATING_TYPES
  * (kernel.cu:1102,1117,1189): *_f32 follows the float instantiation including
