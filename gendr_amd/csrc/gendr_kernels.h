@@ -785,6 +785,9 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
 
     auto run_batch = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
+#if GENDR_ABLATE == 1
+        alpha += (float)npairs; npairs = 0; nfaces = 0; return;
+#endif
         // ---- phase B: one pair per lane
         if (lane < npairs) {
             const PairRecXY pr = s_pair[wave][lane];
@@ -822,6 +825,9 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
             s_res[wave][lane] = res;
         }
         __builtin_amdgcn_wave_barrier();
+#if GENDR_ABLATE == 2
+        alpha += s_res[wave][lane].frag; npairs = 0; nfaces = 0; return;
+#endif
         // ---- phase C: per pixel, faces in ascending order
         for (int s = 0; s < nfaces; s++) {
             const FaceEnt fe = s_face[wave][s];
@@ -961,6 +967,9 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
 
     auto run_batch = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
+#if GENDR_ABLATE == 3
+        npairs = 0; nfaces = 0; return;
+#endif
         if (lane < npairs) {
             const PairRec pr = s_pair[wave][lane];
             const int slot = pr.code >> 8;
@@ -1091,6 +1100,9 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             for (int k = 0; k < NG - 9; k++) s_val[wave][(9 + k) * 65 + lane] = live ? gt[k] : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
+#if GENDR_ABLATE == 4
+        npairs = 0; nfaces = 0; return;
+#endif
         // The pairs of one face are contiguous.  One lane per (face, component) sums its segment in pair order and
         // issues one hardware fp32 atomic: deterministic inside the batch, no LDS atomics.
         for (int e = lane; e < nfaces * NG; e += 64) {
@@ -1098,8 +1110,12 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
             const FaceEnt fe = s_face[wave][slot];
             const int cnt = __popcll(fe.mask);
             const float* col = &s_val[wave][k * 65 + fe.base];
-            float v = 0.f;
-            for (int i = 0; i < cnt; i++) v += col[i];
+            // four independent partial sums so that the LDS reads of a segment overlap instead of chaining
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) { v0 += col[i]; v1 += col[i + 1]; v2 += col[i + 2]; v3 += col[i + 3]; }
+            for (; i < cnt; i++) v0 += col[i];
+            const float v = (v0 + v1) + (v2 + v3);
             if (v != 0.f) {
                 const long face_lin = (long)t.b * a.nf + fe.fn;
                 if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);

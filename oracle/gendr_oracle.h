@@ -12,7 +12,7 @@
  * restatement of that kernel's published arithmetic, written from the source
  * text, citing the lines it follows ("kernel.cu:N").  What pins it instead is
  * listed in DESIGN.md (closed-form CDF/pdf checks against scipy, finite
-* differences of the fp64 build, a second independent restatement in
+ * differences of the fp64 build, a second independent restatement in
  * PyTorch: oracle/torch_ref.py).
  *
  * Two instantiations exist, mirroring AT_DISPATCH_FLOATING_TYPES
