@@ -945,6 +945,13 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
 
+    {   // a tile with an all-zero mask row (background: ~2/3 of the tiles of the headline scene) contributes nothing
+        const unsigned long long* mrow0 = a.masks + (long)t.tile * a.chunks;
+        bool any_face = false;
+        for (int w0 = 0; w0 < a.chunks; w0 += 64)
+            any_face = any_face || __any(w0 + lane < a.chunks && mrow0[w0 + lane] != 0ull);
+        if (!any_face) return;
+    }
     {
         PixIn pi;
 #pragma unroll
