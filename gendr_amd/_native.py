@@ -44,7 +44,8 @@ EXPORTS = (
     "gendr_abi_version", "gendr_params_size", "gendr_error_string", "gendr_workspace_bytes", "gendr_validate",
     "gendr_face_setup", "gendr_forward", "gendr_backward", "gendr_face_info",
     "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
-    "gendr_cull_radius",
+    "gendr_cull_radius", "gendr_project_faces", "gendr_project_faces_backward",
+    "gendr_camera_rotation", "gendr_camera_rotation_backward",
 )
 
 _lib = None
@@ -91,6 +92,14 @@ def lib():
     for name in ("gendr_t_conorm_forward", "gendr_t_conorm_backward"):
         getattr(L, name).restype = f
         getattr(L, name).argtypes = [i, f, f, i, f]
+    L.gendr_camera_rotation.restype = i
+    L.gendr_camera_rotation.argtypes = [vp, vp, vp, vp, i, i, vp]
+    L.gendr_camera_rotation_backward.restype = i
+    L.gendr_camera_rotation_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.gendr_project_faces.restype = i
+    L.gendr_project_faces.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, vp]
+    L.gendr_project_faces_backward.restype = i
+    L.gendr_project_faces_backward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
     L.gendr_cull_radius.restype = f
     L.gendr_cull_radius.argtypes = [pp]
     L.gendr_params_size.restype = i

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "gendr_kernels.h"
+#include "gendr_project.h"
 
 using namespace gendr;
 
@@ -314,6 +315,59 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
     hipLaunchKernelGGL(k.bwd, dim3(a.total_blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+int gendr_camera_rotation(const float* eye, const float* target, const float* up, float* camera, int B,
+                          int target_is_direction, void* stream)
+{
+    if (B < 0) return GENDR_E_SHAPE;
+    if (B == 0) return GENDR_OK;
+    if (!eye || !target || !up || !camera) return GENDR_E_NULL;
+    hipLaunchKernelGGL(camera_rotation_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       eye, target, up, camera, B, target_is_direction);
+    return check_launch();
+}
+
+int gendr_camera_rotation_backward(const float* eye, const float* target, const float* up, const float* grad_camera,
+                                   float* grad_eye, float* grad_target, float* grad_up, int B, int target_is_direction,
+                                   void* stream)
+{
+    if (B < 0) return GENDR_E_SHAPE;
+    if (B == 0) return GENDR_OK;
+    if (!eye || !target || !up || !grad_camera) return GENDR_E_NULL;
+    hipLaunchKernelGGL(camera_rotation_backward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       eye, target, up, grad_camera, grad_eye, grad_target, grad_up, B, target_is_direction);
+    return check_launch();
+}
+
+int gendr_project_faces(const float* vertices, const int* face_index, const float* camera, float* face_vertices,
+                        int B, int nv, int nf, int index_batched, int perspective, float width_or_scale, void* stream)
+{
+    if (B < 0 || nv < 0 || nf < 0) return GENDR_E_SHAPE;
+    if ((long)B * nf == 0) return GENDR_OK;
+    if (!vertices || !face_index || !camera || !face_vertices) return GENDR_E_NULL;
+    const long total = (long)B * nf * 3;
+    const long blocks = (total + kProjThreads - 1) / kProjThreads;
+    if (blocks > 0x7fffffffL) return GENDR_E_SHAPE;
+    hipLaunchKernelGGL(project_faces_kernel, dim3((unsigned)blocks), dim3(kProjThreads), 0, (hipStream_t)stream,
+                       vertices, face_index, camera, face_vertices, B, nv, nf, index_batched, perspective, width_or_scale);
+    return check_launch();
+}
+
+int gendr_project_faces_backward(const float* vertices, const int* face_index, const float* camera,
+                                 const float* grad_face_vertices, float* grad_vertices, float* grad_camera,
+                                 int B, int nv, int nf, int index_batched, int perspective, float width_or_scale, void* stream)
+{
+    if (B < 0 || nv < 0 || nf < 0) return GENDR_E_SHAPE;
+    if ((long)B * nf == 0) return GENDR_OK;
+    if (!vertices || !face_index || !camera || !grad_face_vertices || !grad_vertices) return GENDR_E_NULL;
+    const int blocks_per_item = (int)(((long)nf * 3 + kProjThreads - 1) / kProjThreads);
+    const long blocks = (long)blocks_per_item * B;
+    if (blocks > 0x7fffffffL) return GENDR_E_SHAPE;
+    hipLaunchKernelGGL(project_faces_backward_kernel, dim3((unsigned)blocks), dim3(kProjThreads), 0, (hipStream_t)stream,
+                       vertices, face_index, camera, grad_face_vertices, grad_vertices, grad_camera,
+                       B, nv, nf, index_batched, perspective, width_or_scale, blocks_per_item);
     return check_launch();
 }
 

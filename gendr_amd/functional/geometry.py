@@ -4,7 +4,7 @@ Behavioural counterparts of the reference's ``gendr/functional/look_at.py:11-68`
 ``look.py``, ``get_points_from_angles.py:9-29``, ``face_vertices.py:9-27`` and
 ``gendr/transform.py:14-47`` (``perspective`` / ``orthogonal``).  These are not
 kernels: a handful of elementwise / gather ops; SURVEY.md row f-1 lists fusing
-them into the face staging as the next widening step.
+them; ``projection.py`` is that fusion (HIP), this module stays as the CPU-capable unfused composition.
 """
 import math
 

@@ -1,6 +1,7 @@
 """Camera transforms as ``nn.Module``s mapping a Mesh to a Mesh (plain PyTorch glue; reference
 ``gendr/transform.py:49-168``)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -46,6 +47,46 @@ class Projection(Transform):
         return torch.stack([2 * (xd - half) / self.orig_size, 2 * (yd - half) / self.orig_size, z], dim=-1)
 
 
+class _ProjectedMesh(Mesh):
+    """Mesh seen through a camera.  ``face_vertices`` (what the renderer consumes) comes from the fused HIP
+    projection kernel (``functional/projection.py``); ``vertices`` is still available and is
+    computed by the unfused PyTorch composition on first use."""
+
+    def __init__(self, mesh, camera, eye, target, target_is_direction):
+        self.__dict__.update(mesh.__dict__)
+        self._source_vertices = mesh.vertices
+        self._vertices = None
+        self._camera, self._eye_t, self._target, self._is_dir = camera, eye, target, target_is_direction
+
+    @property
+    def vertices(self):
+        if self._vertices is None:
+            self._vertices = self._camera.transform(self._source_vertices)
+        return self._vertices
+
+    @property
+    def face_vertices(self):
+        cam = self._camera
+        fn = Fn.look_faces if self._is_dir else Fn.look_at_faces
+        return fn(self._source_vertices, self._faces, self._eye_t, self._target, [0., 1., 0.],
+                  cam.perspective, cam.viewing_angle, cam.viewing_scale)
+
+    @property
+    def surface_normals(self):
+        self.vertices
+        return Mesh.surface_normals.fget(self)
+
+    @property
+    def vertex_normals(self):
+        self.vertices
+        return Mesh.vertex_normals.fget(self)
+
+
+def _fused_ok(mesh):
+    return (os.environ.get('GENDR_FUSED_PROJECTION', '1') != '0' and mesh.vertices.is_cuda
+            and mesh.vertices.dtype == torch.float32)
+
+
 class _Camera(Transform):
     def __init__(self, perspective=True, viewing_angle=30, viewing_scale=1.0, eye=None):
         super().__init__()
@@ -74,6 +115,11 @@ class LookAt(_Camera):
     def transform(self, vertices):
         return self._project(Fn.look_at(vertices, self._eye))
 
+    def forward(self, mesh):
+        if not _fused_ok(mesh):
+            return super().forward(mesh)
+        return _ProjectedMesh(mesh, self, self._eye, [0., 0., 0.], False)
+
 
 class Look(_Camera):
     def __init__(self, camera_direction=[0, 0, 1], perspective=True, viewing_angle=30, viewing_scale=1.0, eye=None):
@@ -82,3 +128,8 @@ class Look(_Camera):
 
     def transform(self, vertices):
         return self._project(Fn.look(vertices, self._eye, self.camera_direction))
+
+    def forward(self, mesh):
+        if not _fused_ok(mesh):
+            return super().forward(mesh)
+        return _ProjectedMesh(mesh, self, self._eye, self.camera_direction, True)

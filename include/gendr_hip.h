@@ -113,6 +113,30 @@ float gendr_t_conorm_backward(int t_conorm_id, float a_all, float b_current, int
  * distance exists for the option set.  Used by the face-setup kernel. */
 float gendr_cull_radius(const gendr_params* p);
 
+/* ---- the step right before the hot path, fused ------------------------------------
+ * Replaces the tensor passes of look_at (gendr/functional/look_at.py:59-67: subtract eye, rotate),
+ * perspective / orthogonal (gendr/transform.py:14-47) and the face gather
+ * (gendr/functional/face_vertices.py:24-27) by one kernel each way.
+ *   vertices      [B,nv,3]           in
+ *   face_index    [B or 1,nf,3] i32  in   (index_batched = 1 if it has a batch axis of size B)
+ *   camera        [B,12]             in   rotation rows x_axis, y_axis, z_axis (look_at.py:52-59), then eye
+ *   face_vertices [B,nf,9]           out
+ *   width_or_scale: tan(viewing_angle) if perspective (transform.py:21-23), else the orthogonal scale.
+ * Backward accumulates into zero-filled grad_vertices [B,nv,3] and (optional, may be NULL) grad_camera [B,12]. */
+/* camera [B,12] from eye / target / up [B,3] each (look_at.py:52-59: z = normalize(at - eye), x = normalize(up x z),
+ * y = normalize(z x x), F.normalize eps 1e-5; look.py: z = normalize(direction) when target_is_direction), and its
+ * hand-derived backward (grad_eye / grad_target / grad_up may each be NULL). */
+int gendr_camera_rotation(const float* eye, const float* target, const float* up, float* camera, int B,
+                          int target_is_direction, void* stream);
+int gendr_camera_rotation_backward(const float* eye, const float* target, const float* up, const float* grad_camera,
+                                   float* grad_eye, float* grad_target, float* grad_up, int B, int target_is_direction,
+                                   void* stream);
+int gendr_project_faces(const float* vertices, const int* face_index, const float* camera, float* face_vertices,
+                        int B, int nv, int nf, int index_batched, int perspective, float width_or_scale, void* stream);
+int gendr_project_faces_backward(const float* vertices, const int* face_index, const float* camera,
+                                 const float* grad_face_vertices, float* grad_vertices, float* grad_camera,
+                                 int B, int nv, int nf, int index_batched, int perspective, float width_or_scale, void* stream);
+
 const char* gendr_error_string(int code);
 int gendr_abi_version(void);
 int gendr_params_size(void);   /* sizeof(gendr_params) as compiled, for binding sanity checks */
