@@ -46,6 +46,7 @@ EXPORTS = (
     "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
     "gendr_cull_radius", "gendr_project_faces", "gendr_project_faces_backward",
     "gendr_camera_rotation", "gendr_camera_rotation_backward",
+    "gendr_voxelize_workspace_bytes", "gendr_voxelize",
 )
 
 _lib = None
@@ -92,6 +93,10 @@ def lib():
     for name in ("gendr_t_conorm_forward", "gendr_t_conorm_backward"):
         getattr(L, name).restype = f
         getattr(L, name).argtypes = [i, f, f, i, f]
+    L.gendr_voxelize_workspace_bytes.restype = ctypes.c_size_t
+    L.gendr_voxelize_workspace_bytes.argtypes = [i, i]
+    L.gendr_voxelize.restype = i
+    L.gendr_voxelize.argtypes = [vp, vp, vp, i, i, i, vp]
     L.gendr_camera_rotation.restype = i
     L.gendr_camera_rotation.argtypes = [vp, vp, vp, vp, i, i, vp]
     L.gendr_camera_rotation_backward.restype = i

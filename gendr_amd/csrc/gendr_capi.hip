@@ -10,6 +10,7 @@
 
 #include "gendr_kernels.h"
 #include "gendr_project.h"
+#include "gendr_voxel.h"
 
 using namespace gendr;
 
@@ -315,6 +316,36 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
     hipLaunchKernelGGL(k.bwd, dim3(a.total_blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+size_t gendr_voxelize_workspace_bytes(int B, int voxel_size)
+{
+    if (B <= 0 || voxel_size <= 64) return 0;                  // up to 64^3 the flood fill lives in LDS
+    const size_t W = ((size_t)voxel_size + 63) / 64;
+    return (size_t)B * 2 * voxel_size * voxel_size * W * sizeof(u64);
+}
+
+int gendr_voxelize(const float* faces, int* voxels, void* workspace, int B, int nf, int voxel_size, void* stream)
+{
+    if (B < 0 || nf < 0 || voxel_size < 1 || voxel_size > 1024) return GENDR_E_SHAPE;
+    if (B == 0) return GENDR_OK;
+    if (!voxels || (nf > 0 && !faces)) return GENDR_E_NULL;
+    const int vs = voxel_size, W = (vs + 63) / 64;
+    const bool in_lds = vs <= 64;
+    if (!in_lds && !workspace) return GENDR_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(voxels, 0, (size_t)B * vs * vs * vs * sizeof(int), st) != hipSuccess) return GENDR_E_LAUNCH;
+    if (nf > 0) {
+        const int work = vs * vs > nf ? vs * vs : nf;
+        hipLaunchKernelGGL(voxel_surface_kernel, dim3((work + kVoxSurfaceThreads - 1) / kVoxSurfaceThreads, 4, B),
+                           dim3(kVoxSurfaceThreads), 0, st, faces, voxels, nf, vs);
+    }
+    if (in_lds)
+        hipLaunchKernelGGL(voxel_fill_kernel<true>, dim3(B), dim3(kVoxFillThreads), (size_t)2 * vs * vs * W * sizeof(u64), st,
+                           voxels, (u64*)nullptr, vs, W);
+    else
+        hipLaunchKernelGGL(voxel_fill_kernel<false>, dim3(B), dim3(kVoxFillThreads), 0, st, voxels, (u64*)workspace, vs, W);
     return check_launch();
 }
 

@@ -82,4 +82,28 @@ def save_voxel(filename, voxel):
 
 
 def voxelization(faces, size, normalize=False):
-    raise NotImplementedError('voxelization (SURVEY.md f-2) is outside the rebuilt hot path; not rebuilt yet')
+    """Mesh -> ``[B, size, size, size]`` int32 occupancy (1 = surface or enclosed).  ``faces`` ``[B, nf, 3, 3]`` in
+    unit-cube coordinates (scaled by ``size`` unless ``normalize``; reference ``functional/voxelization.py:47-62``).
+    Two HIP launches (``csrc/gendr_voxel.h``) instead of the reference's four kernels + host-synchronised sweep loop;
+    CUDA tensors only -- there is no CPU path."""
+    from .. import _native
+    from .renderer import check
+    if not torch.is_tensor(faces) or not faces.is_cuda:
+        raise TypeError('voxelization only supports CUDA Tensors')
+    if faces.dim() == 3 and faces.shape[2] == 9:
+        faces = faces.reshape(faces.shape[0], faces.shape[1], 3, 3)
+    if faces.dim() != 4 or faces.shape[2:] != (3, 3):
+        raise ValueError('faces must be [B, nf, 3, 3]; got %s' % (tuple(faces.shape),))
+    size = int(size)
+    faces = faces.detach().to(torch.float32).clone()
+    if not normalize:
+        faces *= size
+    B, nf = faces.shape[:2]
+    lib = _native.lib()
+    voxels = torch.empty(B, size, size, size, dtype=torch.int32, device=faces.device)
+    ws_bytes = lib.gendr_voxelize_workspace_bytes(B, size)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=faces.device) if ws_bytes else None
+    with torch.cuda.device(faces.device):
+        check(lib.gendr_voxelize(faces.data_ptr(), voxels.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                 B, nf, size, torch.cuda.current_stream(faces.device).cuda_stream), 'gendr_voxelize')
+    return voxels

@@ -123,6 +123,15 @@ float gendr_cull_radius(const gendr_params* p);
  *   face_vertices [B,nf,9]           out
  *   width_or_scale: tan(viewing_angle) if perspective (transform.py:21-23), else the orthogonal scale.
  * Backward accumulates into zero-filled grad_vertices [B,nv,3] and (optional, may be NULL) grad_camera [B,12]. */
+/* ---- mesh -> occupancy grid --------------------------------------------------------
+ * Replaces voxelize_sub1 (x3) / sub2 / sub3 / sub4 and the host loop around sub4
+ * (gendr/cuda/voxelization_cuda.cpp:20-89, voxelization_cuda_kernel.cu:36-194, functional/voxelization.py:11-62).
+ *   faces  [B,nf,9]          in   face vertices already in voxel units (voxelization.py:51-52: faces *= size)
+ *   voxels [B,vs,vs,vs] i32  out  1 = surface or enclosed, 0 = reachable from the grid boundary (1 - visible)
+ *   workspace: gendr_voxelize_workspace_bytes(B, vs) bytes (0 for vs <= 64; may then be NULL). */
+size_t gendr_voxelize_workspace_bytes(int B, int voxel_size);
+int gendr_voxelize(const float* faces, int* voxels, void* workspace, int B, int nf, int voxel_size, void* stream);
+
 /* camera [B,12] from eye / target / up [B,3] each (look_at.py:52-59: z = normalize(at - eye), x = normalize(up x z),
  * y = normalize(z x x), F.normalize eps 1e-5; look.py: z = normalize(direction) when target_is_direction), and its
  * hand-derived backward (grad_eye / grad_target / grad_up may each be NULL). */
