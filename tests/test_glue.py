@@ -76,7 +76,7 @@ def test_mesh_transform_chain_and_alias_package(tmp_path):
     assert np.allclose(back.vertices.cpu().numpy(), V[:1].numpy(), atol=1e-6)
     assert np.array_equal(back.faces.cpu().numpy(), Fc[:1].numpy())
     assert np.allclose(back.textures.cpu().numpy(), mv.textures.numpy(), atol=1e-6)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):                 # HIP only, like the renderer: no CPU path
         gendr.functional.voxelization(fv, 32)
 
 
