@@ -46,7 +46,7 @@ EXPORTS = (
     "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
     "gendr_cull_radius", "gendr_project_faces", "gendr_project_faces_backward",
     "gendr_camera_rotation", "gendr_camera_rotation_backward",
-    "gendr_voxelize_workspace_bytes", "gendr_voxelize",
+    "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
 )
 
 _lib = None
@@ -93,6 +93,10 @@ def lib():
     for name in ("gendr_t_conorm_forward", "gendr_t_conorm_backward"):
         getattr(L, name).restype = f
         getattr(L, name).argtypes = [i, f, f, i, f]
+    L.gendr_load_textures.restype = i
+    L.gendr_load_textures.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
+    L.gendr_create_texture_image.restype = i
+    L.gendr_create_texture_image.argtypes = [vp, vp, vp, i, i, i, i, i, f, vp]
     L.gendr_voxelize_workspace_bytes.restype = ctypes.c_size_t
     L.gendr_voxelize_workspace_bytes.argtypes = [i, i]
     L.gendr_voxelize.restype = i

@@ -11,6 +11,7 @@
 #include "gendr_kernels.h"
 #include "gendr_project.h"
 #include "gendr_voxel.h"
+#include "gendr_texture.h"
 
 using namespace gendr;
 
@@ -316,6 +317,32 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
     hipLaunchKernelGGL(k.bwd, dim3(a.total_blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+int gendr_load_textures(const float* image, const float* face_uv, const int* is_update, float* textures,
+                        int nf, int texture_res, int image_height, int image_width, void* stream)
+{
+    if (nf < 0 || texture_res < 1 || image_height < 1 || image_width < 1) return GENDR_E_SHAPE;
+    if (nf == 0) return GENDR_OK;
+    if (!image || !face_uv || !is_update || !textures) return GENDR_E_NULL;
+    const long texels = (long)nf * texture_res * texture_res;
+    hipLaunchKernelGGL(load_textures_kernel, dim3((unsigned)((texels + kTexThreads - 1) / kTexThreads)), dim3(kTexThreads), 0,
+                       (hipStream_t)stream, image, face_uv, is_update, textures, texels, texture_res, image_height, image_width);
+    return check_launch();
+}
+
+int gendr_create_texture_image(const float* face_uv, const float* textures, float* image, int nf, int texture_res_in,
+                               int image_rows, int image_cols, int tile_width, float eps, void* stream)
+{
+    if (nf < 0 || texture_res_in < 1 || image_rows < 1 || image_cols < 1 || tile_width < 1 || image_cols % tile_width)
+        return GENDR_E_SHAPE;
+    if (nf == 0) return GENDR_OK;
+    if (!face_uv || !textures || !image) return GENDR_E_NULL;
+    const long pixels = (long)image_rows * image_cols;
+    hipLaunchKernelGGL(create_texture_image_kernel, dim3((unsigned)((pixels + kTexThreads - 1) / kTexThreads)), dim3(kTexThreads), 0,
+                       (hipStream_t)stream, face_uv, textures, image, pixels, nf, texture_res_in, image_cols / tile_width,
+                       tile_width, eps);
     return check_launch();
 }
 

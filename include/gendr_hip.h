@@ -123,6 +123,18 @@ float gendr_cull_radius(const gendr_params* p);
  *   face_vertices [B,nf,9]           out
  *   width_or_scale: tan(viewing_angle) if perspective (transform.py:21-23), else the orthogonal scale.
  * Backward accumulates into zero-filled grad_vertices [B,nv,3] and (optional, may be NULL) grad_camera [B,12]. */
+/* ---- per-face texel blocks <-> texture atlas ---------------------------------------
+ * gendr_load_textures replaces load_textures (gendr/cuda/load_textures_cuda.cpp, load_textures_cuda_kernel.cu:14-104):
+ *   image [H,W,3] (already flipped vertically by the caller, functional/load_obj.py:104), face_uv [nf,3,2] in [0,1],
+ *   is_update [nf] i32, textures [nf,R*R,3] in/out (faces with is_update == 0 keep their texels).
+ * gendr_create_texture_image replaces create_texture_image (create_texture_image_cuda_kernel.cu:16-112):
+ *   face_uv [nf,3,2] in atlas pixels, textures [nf,R_in*R_in,3], image [rows,cols,3] in/out (pixels of tiles
+ *   without a face keep their value), cols = tile_width * texture_res_out, eps as in functional/save_obj.py:31. */
+int gendr_load_textures(const float* image, const float* face_uv, const int* is_update, float* textures,
+                        int nf, int texture_res, int image_height, int image_width, void* stream);
+int gendr_create_texture_image(const float* face_uv, const float* textures, float* image, int nf, int texture_res_in,
+                               int image_rows, int image_cols, int tile_width, float eps, void* stream);
+
 /* ---- mesh -> occupancy grid --------------------------------------------------------
  * Replaces voxelize_sub1 (x3) / sub2 / sub3 / sub4 and the host loop around sub4
  * (gendr/cuda/voxelization_cuda.cpp:20-89, voxelization_cuda_kernel.cu:36-194, functional/voxelization.py:11-62).
