@@ -34,13 +34,17 @@ struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; };
 #define GENDR_SPECIALISE(D, A, RGB, SQ, TEXM) \
     { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM> }
 
+// same, with the register budget capped for 6 (forward) / 5 (backward) waves per SIMD
+#define GENDR_SPECIALISE_OCC(D, A, RGB, SQ, TEXM) \
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM> }
+
 const KernelEntry kSpecialised[] = {
-    GENDR_SPECIALISE(kUniform,   kProbabilistic, 1, 0, kTexSurface1),   // C2 headline; library defaults
-    GENDR_SPECIALISE(kGaussian,  kEinstein,      1, 1, kTexSurface1),   // C3
-    GENDR_SPECIALISE(kLogistic,  kProbabilistic, 1, 0, kTexSurface1),   // C4
-    GENDR_SPECIALISE(kGamma,     kYager,         1, 0, kTexVertex),     // C5
-    GENDR_SPECIALISE(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // opt_shape / train_reconstruction soft renderer (hard RGB)
-    GENDR_SPECIALISE(kHeaviside, kAlphaHard,     0, 0, kTexSurface1),   // opt_shape hard renderer (opt_shape.py:148-159)
+    GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 1, 0, kTexSurface1),   // C2 headline; library defaults
+    GENDR_SPECIALISE_OCC(kGaussian,  kEinstein,      1, 1, kTexSurface1),   // C3
+    GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 1, 0, kTexSurface1),   // C4
+    GENDR_SPECIALISE(kGamma,         kYager,         1, 0, kTexVertex),     // C5 (gamma's series needs its registers)
+    GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // opt_shape / train_reconstruction soft renderer (hard RGB)
+    GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),   // opt_shape hard renderer (opt_shape.py:148-159)
 };
 
 const KernelEntry kGeneric[3] = {
@@ -70,11 +74,12 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm)
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t boxes_off, records_off, masks_off, total;
-    int tiles_x, chunks, supers_x;
+    size_t boxes_off, records_off, masks_off, lists_off, control_off, total;
+    int tiles_x, chunks, supers_x, ncontrol;
 };
 
 // workspace layout: [cull boxes B*nf*4 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
+//                   [tile queues B*tiles i32][control: queue lengths]
 Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
 {
     Workspace w;
@@ -85,7 +90,10 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.boxes_off = 0;
     w.records_off = align256((size_t)B * nf * 4 * sizeof(float));
     w.masks_off = w.records_off + align256((size_t)B * nf * record_floats(texm) * sizeof(float));
-    w.total = w.masks_off + align256((size_t)B * w.tiles_x * w.tiles_x * w.chunks * sizeof(unsigned long long));
+    w.lists_off = w.masks_off + align256((size_t)B * w.tiles_x * w.tiles_x * w.chunks * sizeof(unsigned long long));
+    w.control_off = w.lists_off + align256((size_t)B * w.tiles_x * w.tiles_x * sizeof(int));
+    w.ncontrol = kCtlInts;
+    w.total = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
     return w;
 }
 
@@ -96,6 +104,8 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     memset(&a, 0, sizeof(a));
     a.records = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + w.records_off);
     a.masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + w.masks_off);
+    a.tile_list = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.lists_off);
+    a.control = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.control_off);
     a.textures = textures;
     a.B = B; a.nf = nf; a.T = T;
     a.R = (int)sqrt((double)T);                                  // kernel.cu:1098
@@ -113,6 +123,14 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.r_zrange = 1. / (double)(p->far_ - p->near_);              // float subtraction first, as kernel.cu:826
     a.r_nzrange = 1. / (double)(p->near_ - p->far_);             // kernel.cu:1026
     return texm;
+}
+
+// Grid of a render kernel: a quarter of one-wave-per-tile (waves stride over their queue), a multiple of 8 so
+// that every XCD gets the same number of workgroups.
+int render_blocks(int total_blocks)
+{
+    const int quarter = (total_blocks + 3) / 4;
+    return ((quarter + 7) / 8) * 8;
 }
 
 int check_launch()
@@ -235,43 +253,53 @@ int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* 
     if (!faces || !faces_info) return GENDR_E_NULL;
     const long total = (long)B * nf;
     if (total == 0) return GENDR_OK;
-    const int blocks = (int)((total + kThreads - 1) / kThreads);
+    // one wavefront per workgroup: 81920 faces are only 1280 wavefronts, spread them over all CUs
+    const int blocks = total > 0 ? (int)((total + 63) / 64) : 1;                        // also zeroes the control block
     hipLaunchKernelGGL(face_info_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, faces, faces_info, total);
     return check_launch();
 }
 
+// face records + cull boxes, tile masks, tile queues
 int gendr_face_setup(const float* faces, const float* textures, void* workspace,
                      int B, int nf, int T, const gendr_params* p, void* stream)
 {
     const int v = gendr_validate(p, B, nf, T);
     if (v != GENDR_OK) return v;
     const long total = (long)B * nf;
-    if (total == 0 || B == 0) return GENDR_OK;
-    if (!faces || !textures) return GENDR_E_NULL;
+    if (B == 0) return GENDR_OK;
     if (!workspace) return GENDR_E_WORKSPACE;
+    if (total > 0 && (!faces || !textures)) return GENDR_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     const int texm = texture_mode(p, T);
     const Workspace w = workspace_layout(B, nf, T, p);
     float* boxes = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.boxes_off);
     float* recs = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.records_off);
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + w.masks_off);
-    const int blocks = (int)((total + kThreads - 1) / kThreads);
+    int* control = reinterpret_cast<int*>(static_cast<char*>(workspace) + w.control_off);
+    // one wavefront per workgroup: 81920 faces are only 1280 wavefronts, spread them over all CUs
+    const int blocks = total > 0 ? (int)((total + 63) / 64) : 1;                        // also zeroes the control block
     const float sthr = sqrtf(p->dist_eps * p->dist_scale);       // sqrt(threshold), kernel.cu:725,747
     const float cull_r = gendr_cull_radius(p);
     if (texm == kTexSurface1)
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol);
     else if (texm == kTexVertex)
-        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
+        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol);
     else
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(kThreads), 0, s, faces, textures, boxes, recs, total, sthr, cull_r);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol);
     int e = check_launch();
     if (e != GENDR_OK) return e;
     // one wavefront per (image, 64x64 super-tile, 64-face chunk)
     const long waves = (long)B * w.supers_x * w.supers_x * w.chunks;
     const long bblocks = (waves + (kThreads / 64) - 1) / (kThreads / 64);
     if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
-    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kThreads), 0, s, boxes, masks,
+    if (bblocks > 0)
+        hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kThreads), 0, s, boxes, masks,
                        B, nf, p->image_size, w.tiles_x, w.chunks, w.supers_x, p->cull);
+    e = check_launch();
+    if (e != GENDR_OK) return e;
+    RenderArgs a;
+    fill_args(a, workspace, textures, B, nf, T, p);
+    hipLaunchKernelGGL(tile_list_kernel, dim3((a.tiles_per_image + kThreads - 1) / kThreads, B), dim3(kThreads), 0, s, a);
     return check_launch();
 }
 
@@ -282,7 +310,7 @@ int gendr_forward(const float* faces, const float* textures, float* rgba, float*
     if (v != GENDR_OK) return v;
     if (!rgba || !aggrs_info) return GENDR_E_NULL;
     if (B == 0) return GENDR_OK;
-    if (nf > 0 && !workspace) return GENDR_E_WORKSPACE;
+    if (!workspace) return GENDR_E_WORKSPACE;
     const int e = gendr_face_setup(faces, textures, workspace, B, nf, T, p, stream);
     if (e != GENDR_OK) return e;
 
@@ -291,7 +319,7 @@ int gendr_forward(const float* faces, const float* textures, float* rgba, float*
     a.rgba = rgba;
     a.aux = aggrs_info;
     const KernelEntry& k = pick_kernel(p, texm);
-    hipLaunchKernelGGL(k.fwd, dim3(a.total_blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -316,7 +344,7 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.grad_textures = grad_textures;
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
-    hipLaunchKernelGGL(k.bwd, dim3(a.total_blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

@@ -114,6 +114,21 @@ __host__ __device__ constexpr int record_floats(int texm) { return texm == kTexS
 constexpr int kTile    = 8;     // one wavefront renders an 8x8 pixel tile
 constexpr int kThreads = 256;   // 4 independent wave-tiles per workgroup
 
+// Control block (ints) at the end of the workspace, zeroed by face_setup_kernel on every call:
+//   [x * kCtlStride], x = 0..7     : length of tile queue x,
+//   [(8 + x) * kCtlStride]         : number of tiles of the same images that list no face.
+// The 16 counters sit 4 KiB apart: device-scope atomics execute at the memory side and atomics to one line
+// serialise (~13 ns each, measured), so counters that share a line would make the list kernel atomic-bound.
+// Queue x holds the listed tiles (global tile ids) of images [x*B/8, (x+1)*B/8) and occupies the slots of those
+// images in tile_list, growing from the front; the unlisted tiles of those images grow from the back.  Workgroups are dispatched round-robin over the 8 XCDs, so the waves of workgroups with
+// blockIdx.x & 7 == x walk queue x: all tiles of an image are rendered through one XCD's L2, which then holds that
+// image's face records and mask rows once.  (If the dispatch order were different every tile would still be
+// rendered exactly once; only the locality would suffer.)
+constexpr int kCtlStride = 1024, kCtlInts = 16 * kCtlStride;
+
+// queue that holds the tiles of image b: the x with (x*B)>>3 <= b < ((x+1)*B)>>3
+__device__ __forceinline__ int queue_of_image(int b, int B) { return min(7, (8 * (b + 1) + B - 1) / B - 1); }
+
 struct RenderArgs {
     const float*  records;      // [B*nf][REC]
     const unsigned long long* masks;   // [B*tiles][chunks] : bit f of chunk c set = face 64c+f may touch the tile
@@ -123,6 +138,8 @@ struct RenderArgs {
     const float*  grad_rgba;    // backward only
     float*        grad_faces;   // backward only
     float*        grad_textures;
+    int*          tile_list;    // [B * tiles_per_image]: 8 queues of global tile ids, see kCtlInts
+    int*          control;      // queue lengths
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
     gendr_params p;
@@ -193,10 +210,11 @@ template <int TEXM>
 __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const float* __restrict__ faces, const float* __restrict__ textures,
     float* __restrict__ boxes, float* __restrict__ records,
-    long total_faces, float sthr, float cull_r)
+    long total_faces, float sthr, float cull_r, int* __restrict__ control, int ncontrol)
 {
     constexpr int REC = record_floats(TEXM);
-    const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // launched with one wavefront per workgroup
+    if (i < ncontrol / kCtlStride) control[i * kCtlStride] = 0;                         // queue counters for this call
     if (i >= total_faces) return;
     float f[9];
 #pragma unroll
@@ -422,12 +440,26 @@ __device__ __forceinline__ void pair_pixel(float& xp, float& yp, const TileCtx& 
     yp = pixel_coord(is - 1 - row, is);
 }
 
-__device__ __forceinline__ bool tile_setup(TileCtx& t, const RenderArgs& a)
+// The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
+// own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
+// tiles list a face) that is one tile per wave and no wave is launched in vain.
+struct TileWalk { long qbase, qend; int total, empties, rank, next, stride; };
+
+__device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int waves_per_block)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // 4 consecutive tiles of an image row per workgroup; uniform per wave
-    const int tile = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, a.total_blocks) * (kThreads / 64) + wave);
-    if (tile >= a.total_tiles) return false;
+    const int xcd = blockIdx.x & 7;                                          // gridDim.x is a multiple of 8
+    w.qbase = (long)((xcd * a.B) >> 3) * a.tiles_per_image;
+    w.qend = (long)(((xcd + 1) * a.B) >> 3) * a.tiles_per_image;
+    w.total = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride]);
+    w.empties = __builtin_amdgcn_readfirstlane(a.control[(8 + xcd) * kCtlStride]);
+    w.stride = (int)(gridDim.x >> 3) * waves_per_block;
+    w.rank = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * waves_per_block + (int)(threadIdx.x >> 6));
+    w.next = w.rank;
+}
+
+__device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int tile)
+{
+    const int lane = threadIdx.x & 63;
     t.tile = tile;
     t.b = tile / a.tiles_per_image;
     const int tl = tile - t.b * a.tiles_per_image;
@@ -438,7 +470,6 @@ __device__ __forceinline__ bool tile_setup(TileCtx& t, const RenderArgs& a)
     t.xp = pixel_coord(t.xi, a.is);
     t.yp = pixel_coord(a.is - 1 - t.row, a.is);   // yi = is - 1 - row, kernel.cu:716
     t.pix = (long)t.row * a.is + t.xi;
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -739,6 +770,71 @@ __device__ __forceinline__ void for_each_listed_face(const RenderArgs& a, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// tile lists + background
+// ---------------------------------------------------------------------------------------------
+// One lane per tile, one wavefront per 64 consecutive tiles of an image.  Tiles whose mask row lists at least one
+// face are appended to their image's queue (one atomic per wavefront); the render loops only ever see those.
+// Tiles that list none -- the background, three quarters of the headline scene -- are collected at the back of the
+// queue's slots; the forward kernel writes their pixels in a store-only loop, backward never looks at them.
+// grid: (blocks per image, B); the 4 wavefronts of a workgroup combine their counts in LDS so that a workgroup costs
+// two atomics (atomics to one line serialise, see kCtlStride).
+__global__ __launch_bounds__(kThreads) void tile_list_kernel(const RenderArgs a)
+{
+    constexpr int WAVES = kThreads / 64;
+    __shared__ int s_cnt[WAVES][2];
+    __shared__ int s_base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int b = blockIdx.y;
+    const int tl0 = (blockIdx.x * WAVES + wave) << 6;
+    const int tl = tl0 + lane;
+    const bool valid = tl < a.tiles_per_image;
+    // The 64 mask rows of this wavefront are one contiguous block of 64 * chunks words: read it with coalesced
+    // loads (lane = word), ballot "word != 0", and let lane r test the bits of its own row [r*chunks, (r+1)*chunks).
+    bool any = false;
+    if (tl0 < a.tiles_per_image) {
+        const long words_left = ((long)a.tiles_per_image - tl0) * a.chunks;      // rows past the image end are not read
+        const unsigned long long* blk = a.masks + ((long)b * a.tiles_per_image + tl0) * a.chunks;
+        const int lo = lane * a.chunks, hi = lo + a.chunks;
+        for (int i0 = 0; i0 < a.chunks; i0 += 8) {                             // 8 loads in flight, then their ballots
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int w = (i0 + u) * 64 + lane;
+                v[u] = (i0 + u < a.chunks && w < words_left) ? blk[w] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u;
+                const unsigned long long nz = __ballot(v[u] != 0ull);
+                const int s0 = max(lo, i * 64) - i * 64, s1 = min(hi, i * 64 + 64) - i * 64;
+                if (s0 < s1) {
+                    const unsigned long long span = (s1 - s0 == 64 ? ~0ull : ((1ull << (s1 - s0)) - 1ull)) << s0;
+                    any = any || (nz & span) != 0ull;
+                }
+            }
+        }
+    }
+    const unsigned long long listed = __ballot(valid && any);
+    const unsigned long long empty = __ballot(valid && !any);
+    if (lane == 0) { s_cnt[wave][0] = __popcll(listed); s_cnt[wave][1] = __popcll(empty); }
+    __syncthreads();
+    const int x = queue_of_image(b, a.B);
+    if (threadIdx.x < 2) {
+        int n = 0;
+        for (int w = 0; w < WAVES; w++) n += s_cnt[w][threadIdx.x];
+        s_base[threadIdx.x] = n ? atomicAdd(a.control + (8 * threadIdx.x + x) * kCtlStride, n) : 0;
+    }
+    __syncthreads();
+    int base_l = s_base[0], base_e = s_base[1];
+    for (int w = 0; w < wave; w++) { base_l += s_cnt[w][0]; base_e += s_cnt[w][1]; }
+    if (valid && any)
+        a.tile_list[(long)((x * a.B) >> 3) * a.tiles_per_image + base_l + __popcll(listed & lt)] = b * a.tiles_per_image + tl;
+    if (valid && !any)
+        a.tile_list[(long)(((x + 1) * a.B) >> 3) * a.tiles_per_image - 1 - (base_e + __popcll(empty & lt))] = b * a.tiles_per_image + tl;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 struct FwdRes {            // 32 bytes: what phase C needs from a pair
@@ -750,7 +846,7 @@ struct FwdRes {            // 32 bytes: what phase C needs from a pair
 };
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
-__global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderArgs a)
+__device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int WAVES = kThreads / 64;
@@ -758,14 +854,19 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
     __shared__ __attribute__((aligned(16))) FwdRes  s_res[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
 
-    TileCtx t;
-    if (!tile_setup(t, a)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
     const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
+
+    TileWalk tw;
+    walk_init(tw, a, WAVES);
+    for (; tw.next < tw.total; tw.next += tw.stride) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    TileCtx t;
+    tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]));
 
     // per-pixel state, kernel.cu:728-740
     float bg[3];
@@ -895,22 +996,65 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
     });
     if (npairs > 0) run_batch();
 
-    if (!t.valid) return;
-    // epilogue, kernel.cu:845-861
-    float* out = a.rgba + (long)t.b * 4 * P + t.pix;
-    float* aux = a.aux + (long)t.b * 2 * P + t.pix;
-    out[3 * P] = alpha;
-    if (!rgb_soft) {
+    if (t.valid) {
+        // epilogue, kernel.cu:845-861
+        float* out = a.rgba + (long)t.b * 4 * P + t.pix;
+        float* aux = a.aux + (long)t.b * 2 * P + t.pix;
+        out[3 * P] = alpha;
+        if (!rgb_soft) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) out[k * P] = (face_min != -1) ? col[k] : bg[k];
-        aux[0] = depth_min;
-        aux[P] = (float)face_min;
-    } else {
+            for (int k = 0; k < 3; k++) out[k * P] = (face_min != -1) ? col[k] : bg[k];
+            aux[0] = depth_min;
+            aux[P] = (float)face_min;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; k++) out[k * P] = col[k] / ssum;
-        aux[0] = ssum;
-        aux[P] = smax;
+            for (int k = 0; k < 3; k++) out[k * P] = col[k] / ssum;
+            aux[0] = ssum;
+            aux[P] = smax;
+        }
     }
+    __builtin_amdgcn_wave_barrier();
+    }   // tile loop
+
+    // Tiles no face is listed for: what the loop above leaves for an untouched pixel (kernel.cu:728-740, :845-861).
+    for (int r = tw.rank; r < tw.empties; r += tw.stride) {
+        TileCtx t;
+        tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]));
+        if (!t.valid) continue;
+        float* out = a.rgba + (long)t.b * 4 * P + t.pix;
+        float* aux = a.aux + (long)t.b * 2 * P + t.pix;
+        out[3 * P] = 0.f;
+        if (!rgb_soft) {
+            if (!a.p.background_from_buffer) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) out[k * P] = a.p.background[k];
+            }
+            aux[0] = 10000000.f;
+            aux[P] = -1.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float bgk = a.p.background_from_buffer ? out[k * P] : a.p.background[k];
+                out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0;
+            }
+            aux[0] = a.softmax_sum0;
+            aux[P] = a.p.aggr_rgb_eps;
+        }
+    }
+}
+
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderArgs a)
+{
+    render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+
+// Same body, register budget capped for 6 waves per SIMD (80 VGPRs): used for the specialised option sets, whose
+// natural allocation sits a few registers above that step; the handful of spilled dwords costs less than the wave.
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6))) void render_forward_kernel_w6(const RenderArgs a)
+{
+    render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -923,7 +1067,7 @@ struct PixIn {             // 40 bytes: per-pixel inputs of the backward pass, k
 };
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
-__global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderArgs a)
+__device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int NG = GradSlots<TEXM>::n;       // 9 vertex components, then texture components summed per face in LDS
@@ -934,10 +1078,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
     __shared__ float s_val[WAVES][NG * 65];      // per-pair gradient partials, component-major, rows padded to 65
 
-    TileCtx t;
-    if (!tile_setup(t, a)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
     const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
@@ -945,13 +1086,13 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
 
-    {   // a tile with an all-zero mask row (background: ~2/3 of the tiles of the headline scene) contributes nothing
-        const unsigned long long* mrow0 = a.masks + (long)t.tile * a.chunks;
-        bool any_face = false;
-        for (int w0 = 0; w0 < a.chunks; w0 += 64)
-            any_face = any_face || __any(w0 + lane < a.chunks && mrow0[w0 + lane] != 0ull);
-        if (!any_face) return;
-    }
+    TileWalk tw;
+    walk_init(tw, a, WAVES);
+    for (; tw.next < tw.total; tw.next += tw.stride) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    TileCtx t;
+    tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]));
     {
         PixIn pi;
 #pragma unroll
@@ -1155,6 +1296,21 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
         nfaces += 1;
     });
     if (npairs > 0) run_batch();
+    __builtin_amdgcn_wave_barrier();
+    }   // tile loop
+}
+
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderArgs a)
+{
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+
+// register budget capped for 5 waves per SIMD (96 VGPRs), see render_forward_kernel_w6
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void render_backward_kernel_w5(const RenderArgs a)
+{
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
 
 }  // namespace gendr

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GENDR_ABI_VERSION 1
+#define GENDR_ABI_VERSION 2
 
 enum {
     GENDR_OK              = 0,
@@ -90,7 +90,8 @@ int gendr_forward(const float* faces, const float* textures, float* rgba, float*
 
 /* replaces backward_render (generalized_renderer_cuda.cpp:130-192 -> kernel.cu:1155-1227).
  *   grad_faces [B,nf,9] and grad_textures [B,nf,T,3] must be zero-filled by the
- *   caller (functional/renderer.py:191-196); gradients are accumulated into them. */
+ *   caller (functional/renderer.py:191-196); gradients are accumulated into them.
+ *   workspace: as left by gendr_forward / gendr_face_setup (read only). */
 int gendr_backward(const float* faces, const float* textures, const float* rgba, const float* aggrs_info,
                    const void* workspace, const float* grad_rgba,
                    float* grad_faces, float* grad_textures,

@@ -77,9 +77,11 @@ def test_validate_shapes(native_lib):
 
 def test_workspace_bytes(native_lib):
     p = _params(image_size=256)
-    # boxes 16 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk); every part 256-byte aligned
+    # boxes 16 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile lists 4 B per tile,
+    # control block (queue lengths); every part 256-byte aligned
     n = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(p))
-    assert n == 2 * 1280 * 16 + 2 * 1280 * 224 + 2 * 32 * 32 * 20 * 8
+    control = 16 * 1024 * 4                  # 16 counters, 4 KiB apart
+    assert n == 2 * 1280 * 16 + 2 * 1280 * 224 + 2 * 32 * 32 * 20 * 8 + 2 * 32 * 32 * 4 + control
     assert native_lib.gendr_workspace_bytes(2, 1280, 3, ctypes.byref(_params(image_size=256, texture_type='vertex'))) > n
     assert native_lib.gendr_workspace_bytes(2, 1280, 0, ctypes.byref(p)) == 0
 
