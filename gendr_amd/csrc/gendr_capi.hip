@@ -299,7 +299,7 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     if (e != GENDR_OK) return e;
     RenderArgs a;
     fill_args(a, workspace, textures, B, nf, T, p);
-    hipLaunchKernelGGL(tile_list_kernel, dim3((a.tiles_per_image + kThreads - 1) / kThreads, B), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(tile_list_kernel, dim3((unsigned)(((long)a.total_tiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a);
     return check_launch();
 }
 

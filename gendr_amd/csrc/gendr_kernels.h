@@ -116,18 +116,20 @@ constexpr int kThreads = 256;   // 4 independent wave-tiles per workgroup
 
 // Control block (ints) at the end of the workspace, zeroed by face_setup_kernel on every call:
 //   [x * kCtlStride], x = 0..7     : length of tile queue x,
-//   [(8 + x) * kCtlStride]         : number of tiles of the same images that list no face.
+//   [(8 + x) * kCtlStride]         : number of tiles of the same range that list no face.
 // The 16 counters sit 4 KiB apart: device-scope atomics execute at the memory side and atomics to one line
 // serialise (~13 ns each, measured), so counters that share a line would make the list kernel atomic-bound.
-// Queue x holds the listed tiles (global tile ids) of images [x*B/8, (x+1)*B/8) and occupies the slots of those
-// images in tile_list, growing from the front; the unlisted tiles of those images grow from the back.  Workgroups are dispatched round-robin over the 8 XCDs, so the waves of workgroups with
-// blockIdx.x & 7 == x walk queue x: all tiles of an image are rendered through one XCD's L2, which then holds that
-// image's face records and mask rows once.  (If the dispatch order were different every tile would still be
-// rendered exactly once; only the locality would suffer.)
+// Queue x holds the listed tiles among global tile ids [x*N/8, (x+1)*N/8), N = B * tiles_per_image -- whole images
+// when B is a multiple of 8, bands of an image when B is small -- and occupies those slots of tile_list, growing
+// from the front; the unlisted tiles of the range grow from the back.  Workgroups are dispatched round-robin over
+// the 8 XCDs, so the waves of workgroups with blockIdx.x & 7 == x walk queue x: the tiles of an image (band) are
+// rendered through one XCD's L2, which then holds that image's face records and mask rows once.  (If the dispatch
+// order were different every tile would still be rendered exactly once; only the locality would suffer.)
 constexpr int kCtlStride = 1024, kCtlInts = 16 * kCtlStride;
 
-// queue that holds the tiles of image b: the x with (x*B)>>3 <= b < ((x+1)*B)>>3
-__device__ __forceinline__ int queue_of_image(int b, int B) { return min(7, (8 * (b + 1) + B - 1) / B - 1); }
+__device__ __forceinline__ long queue_begin(int x, long n_tiles) { return ((long)x * n_tiles) >> 3; }
+// the x with queue_begin(x) <= g < queue_begin(x + 1)
+__device__ __forceinline__ int queue_of_tile(long g, long n_tiles) { return (int)min(7L, (8 * (g + 1) + n_tiles - 1) / n_tiles - 1); }
 
 struct RenderArgs {
     const float*  records;      // [B*nf][REC]
@@ -448,8 +450,8 @@ struct TileWalk { long qbase, qend; int total, empties, rank, next, stride; };
 __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int waves_per_block)
 {
     const int xcd = blockIdx.x & 7;                                          // gridDim.x is a multiple of 8
-    w.qbase = (long)((xcd * a.B) >> 3) * a.tiles_per_image;
-    w.qend = (long)(((xcd + 1) * a.B) >> 3) * a.tiles_per_image;
+    w.qbase = queue_begin(xcd, a.total_tiles);
+    w.qend = queue_begin(xcd + 1, a.total_tiles);
     w.total = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride]);
     w.empties = __builtin_amdgcn_readfirstlane(a.control[(8 + xcd) * kCtlStride]);
     w.stride = (int)(gridDim.x >> 3) * waves_per_block;
@@ -776,25 +778,20 @@ __device__ __forceinline__ void for_each_listed_face(const RenderArgs& a, const 
 // face are appended to their image's queue (one atomic per wavefront); the render loops only ever see those.
 // Tiles that list none -- the background, three quarters of the headline scene -- are collected at the back of the
 // queue's slots; the forward kernel writes their pixels in a store-only loop, backward never looks at them.
-// grid: (blocks per image, B); the 4 wavefronts of a workgroup combine their counts in LDS so that a workgroup costs
-// two atomics (atomics to one line serialise, see kCtlStride).
 __global__ __launch_bounds__(kThreads) void tile_list_kernel(const RenderArgs a)
 {
-    constexpr int WAVES = kThreads / 64;
-    __shared__ int s_cnt[WAVES][2];
-    __shared__ int s_base[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int b = blockIdx.y;
-    const int tl0 = (blockIdx.x * WAVES + wave) << 6;
-    const int tl = tl0 + lane;
-    const bool valid = tl < a.tiles_per_image;
+    const long g0 = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) << 6;     // first global tile id of this wave
+    if (g0 >= a.total_tiles) return;
+    const long g = g0 + lane;
+    const bool valid = g < a.total_tiles;
     // The 64 mask rows of this wavefront are one contiguous block of 64 * chunks words: read it with coalesced
     // loads (lane = word), ballot "word != 0", and let lane r test the bits of its own row [r*chunks, (r+1)*chunks).
     bool any = false;
-    if (tl0 < a.tiles_per_image) {
-        const long words_left = ((long)a.tiles_per_image - tl0) * a.chunks;      // rows past the image end are not read
-        const unsigned long long* blk = a.masks + ((long)b * a.tiles_per_image + tl0) * a.chunks;
+    {
+        const long words_left = (a.total_tiles - g0) * a.chunks;              // rows past the end are not read
+        const unsigned long long* blk = a.masks + g0 * a.chunks;
         const int lo = lane * a.chunks, hi = lo + a.chunks;
         for (int i0 = 0; i0 < a.chunks; i0 += 8) {                             // 8 loads in flight, then their ballots
             unsigned long long v[8];
@@ -815,23 +812,25 @@ __global__ __launch_bounds__(kThreads) void tile_list_kernel(const RenderArgs a)
             }
         }
     }
-    const unsigned long long listed = __ballot(valid && any);
-    const unsigned long long empty = __ballot(valid && !any);
-    if (lane == 0) { s_cnt[wave][0] = __popcll(listed); s_cnt[wave][1] = __popcll(empty); }
-    __syncthreads();
-    const int x = queue_of_image(b, a.B);
-    if (threadIdx.x < 2) {
-        int n = 0;
-        for (int w = 0; w < WAVES; w++) n += s_cnt[w][threadIdx.x];
-        s_base[threadIdx.x] = n ? atomicAdd(a.control + (8 * threadIdx.x + x) * kCtlStride, n) : 0;
+    // usually the 64 tiles belong to one queue; small batches of small images put several queues into one wave
+    const int xq = valid ? queue_of_tile(g, a.total_tiles) : -1;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
+        const unsigned long long mine = __ballot(xq == x);
+        todo &= ~mine;
+        const unsigned long long listed = __ballot(xq == x && any);
+        const unsigned long long empty = mine & ~listed;
+        int base_l = 0, base_e = 0;
+        if (lane == 0) {
+            if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
+            if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
+        }
+        base_l = __builtin_amdgcn_readfirstlane(base_l);
+        base_e = __builtin_amdgcn_readfirstlane(base_e);
+        if ((listed >> lane) & 1ull) a.tile_list[queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt)] = (int)g;
+        if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
     }
-    __syncthreads();
-    int base_l = s_base[0], base_e = s_base[1];
-    for (int w = 0; w < wave; w++) { base_l += s_cnt[w][0]; base_e += s_cnt[w][1]; }
-    if (valid && any)
-        a.tile_list[(long)((x * a.B) >> 3) * a.tiles_per_image + base_l + __popcll(listed & lt)] = b * a.tiles_per_image + tl;
-    if (valid && !any)
-        a.tile_list[(long)(((x + 1) * a.B) >> 3) * a.tiles_per_image - 1 - (base_e + __popcll(empty & lt))] = b * a.tiles_per_image + tl;
 }
 
 // ---------------------------------------------------------------------------------------------
