@@ -32,6 +32,18 @@
 #include "../../include/gendr_hip.h"
 #include "gendr_math.h"
 
+// register budgets of the occupancy-capped kernel variants (waves per SIMD)
+#ifndef GENDR_FWD_WAVES
+#define GENDR_FWD_WAVES 6
+#endif
+#ifndef GENDR_BWD_WAVES
+#define GENDR_BWD_WAVES 5
+#endif
+
+#ifndef GENDR_SPLIT_MIN
+#define GENDR_SPLIT_MIN 8
+#endif
+
 #ifndef GENDR_ABLATE
 #define GENDR_ABLATE 0   // diagnostic builds only (tools/): 1..3 cut the forward loop short after a stage
 #endif
@@ -113,6 +125,7 @@ __host__ __device__ constexpr int record_floats(int texm) { return texm == kTexS
 
 constexpr int kTile    = 8;     // one wavefront renders an 8x8 pixel tile
 constexpr int kThreads = 256;   // 4 independent wave-tiles per workgroup
+constexpr int kSplitMin = GENDR_SPLIT_MIN;   // a face's pairs are split over two batches if at least this many fit into the open one
 
 // Control block (ints) at the end of the workspace, zeroed by face_setup_kernel on every call:
 //   [x * kCtlStride], x = 0..7     : length of tile queue x,
@@ -975,23 +988,35 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 
     for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
         Pair q;
-        const unsigned long long m = collect_pairs<REC>(t, rp, q);
+        unsigned long long m = collect_pairs<REC>(t, rp, q);
         if (!m) return;
-        const int cnt = __popcll(m);
-        if (npairs + cnt > 64) run_batch();
-        if ((m >> lane) & 1ull) {
-            PairRecXY pr;
-            pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
-            pr.code = (nfaces << 8) | lane; pr.xp = t.xp; pr.yp = t.yp; pr.pad0 = 0; pr.pad1 = 0;
-            s_pair[wave][npairs + __popcll(m & lt)] = pr;
+        auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
+            if ((mm >> lane) & 1ull) {
+                PairRecXY pr;
+                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
+                pr.code = (nfaces << 8) | lane; pr.xp = t.xp; pr.yp = t.yp; pr.pad0 = 0; pr.pad1 = 0;
+                s_pair[wave][npairs + __popcll(mm & lt)] = pr;
+            }
+            if (lane == 0) {
+                FaceEnt fe;
+                fe.fn = fn; fe.base = npairs; fe.mask = mm;
+                s_face[wave][nfaces] = fe;
+            }
+            npairs += __popcll(mm);
+            nfaces += 1;
+        };
+        if (npairs + __popcll(m) > 64) {
+            // top the batch up with the first pairs of this face (its pixels stay in ascending-face order: the rest
+            // of the face opens the next batch), unless the room left is not worth a second list entry
+            const int room = 64 - npairs;
+            if (room >= kSplitMin) {
+                const unsigned long long m1 = __ballot(((m >> lane) & 1ull) && __popcll(m & lt) < room);
+                emit(m1);
+                m &= ~m1;
+            }
+            run_batch();
         }
-        if (lane == 0) {
-            FaceEnt fe;
-            fe.fn = fn; fe.base = npairs; fe.mask = m;
-            s_face[wave][nfaces] = fe;
-        }
-        npairs += cnt;
-        nfaces += 1;
+        emit(m);
     });
     if (npairs > 0) run_batch();
 
@@ -1051,7 +1076,7 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
 // Same body, register budget capped for 6 waves per SIMD (80 VGPRs): used for the specialised option sets, whose
 // natural allocation sits a few registers above that step; the handful of spilled dwords costs less than the wave.
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6))) void render_forward_kernel_w6(const RenderArgs a)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_FWD_WAVES))) void render_forward_kernel_w6(const RenderArgs a)
 {
     render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
@@ -1276,23 +1301,33 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 
     for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
         Pair q;
-        const unsigned long long m = collect_pairs<REC>(t, rp, q);
+        unsigned long long m = collect_pairs<REC>(t, rp, q);
         if (!m) return;
-        const int cnt = __popcll(m);
-        if (npairs + cnt > 64) run_batch();
-        if ((m >> lane) & 1ull) {
-            PairRec pr;
-            pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
-            pr.code = (nfaces << 8) | lane;
-            s_pair[wave][npairs + __popcll(m & lt)] = pr;
+        auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
+            if ((mm >> lane) & 1ull) {
+                PairRec pr;
+                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
+                pr.code = (nfaces << 8) | lane;
+                s_pair[wave][npairs + __popcll(mm & lt)] = pr;
+            }
+            if (lane == 0) {
+                FaceEnt fe;
+                fe.fn = fn; fe.base = npairs; fe.mask = mm;
+                s_face[wave][nfaces] = fe;
+            }
+            npairs += __popcll(mm);
+            nfaces += 1;
+        };
+        if (npairs + __popcll(m) > 64) {
+            const int room = 64 - npairs;                       // top the batch up, see render_forward_body
+            if (room >= kSplitMin) {
+                const unsigned long long m1 = __ballot(((m >> lane) & 1ull) && __popcll(m & lt) < room);
+                emit(m1);
+                m &= ~m1;
+            }
+            run_batch();
         }
-        if (lane == 0) {
-            FaceEnt fe;
-            fe.fn = fn; fe.base = npairs; fe.mask = m;
-            s_face[wave][nfaces] = fe;
-        }
-        npairs += cnt;
-        nfaces += 1;
+        emit(m);
     });
     if (npairs > 0) run_batch();
     __builtin_amdgcn_wave_barrier();
@@ -1307,7 +1342,7 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
 
 // register budget capped for 5 waves per SIMD (96 VGPRs), see render_forward_kernel_w6
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void render_backward_kernel_w5(const RenderArgs a)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BWD_WAVES))) void render_backward_kernel_w5(const RenderArgs a)
 {
     render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
