@@ -161,6 +161,13 @@ def native_backward(faces, textures, rgba, aggrs_info, records, grad_rgba, param
     B, nf = faces.shape[0], faces.shape[1]
     T = textures.shape[2]
     dev = faces.device
+    if grad_faces is None and grad_textures is None:
+        # one zero fill for both gradients (they are small: one launch instead of two)
+        n_f, n_t = B * nf * 9, textures.numel()
+        n_f_pad = (n_f + 63) // 64 * 64                    # keep grad_textures 256-byte aligned
+        flat = torch.zeros(n_f_pad + n_t, dtype=torch.float32, device=dev)
+        grad_faces = flat[:n_f].view(B, nf, 9)
+        grad_textures = flat[n_f_pad:].view(textures.shape)
     if grad_faces is None:
         grad_faces = torch.zeros((B, nf, 9), dtype=torch.float32, device=dev)
     if grad_textures is None:
