@@ -440,6 +440,7 @@ __global__ __launch_bounds__(kThreads) void bin_faces_kernel(
 struct TileCtx {
     int   b;            // batch item
     int   tile;         // global tile id (b * tiles_per_image + ty * tiles_x + tx)
+    int   x0, y0;       // first pixel column / row of the tile (uniform)
     int   xi, row;      // this lane's pixel
     bool  valid;        // pixel inside the image
     float xp, yp;       // pixel centre, kernel.cu:716-719
@@ -479,8 +480,10 @@ __device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int 
     t.b = tile / a.tiles_per_image;
     const int tl = tile - t.b * a.tiles_per_image;
     const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
-    t.xi = tx * kTile + (lane & 7);
-    t.row = ty * kTile + (lane >> 3);
+    t.x0 = tx * kTile;
+    t.y0 = ty * kTile;
+    t.xi = t.x0 + (lane & 7);
+    t.row = t.y0 + (lane >> 3);
     t.valid = t.xi < a.is && t.row < a.is;
     t.xp = pixel_coord(t.xi, a.is);
     t.yp = pixel_coord(a.is - 1 - t.row, a.is);   // yi = is - 1 - row, kernel.cu:716
@@ -708,10 +711,10 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 //                      CU as one hardware fp32 atomic per (tile batch, face, component).
 // Everything is wavefront-local: no barriers.
 // ---------------------------------------------------------------------------------------------
-struct PairRec {           // 16 bytes
-    float w0, w1, w2;      // barycentrics of the pixel w.r.t. the face (:39-43)
-    int   code;            // (face slot in the batch << 8) | pixel lane
-};
+// A pair in the batch list is one int: (face slot in the batch << 8) | pixel lane.  Its barycentrics are computed in
+// phase B from the gathered record (the same expressions on the same operands as everywhere else).
+// Forward keeps the scalar-load phase A below (collect_pairs): its phase B has no registers to spare for the
+// barycentrics, so they travel with the pair, as does the pixel centre.
 struct PairRecXY {         // 32 bytes: forward keeps the pixel centre with the pair (its LDS budget allows it,
     float w0, w1, w2;      // and recomputing it costs the forward kernel an occupancy step in registers)
     int   code;
@@ -740,6 +743,7 @@ __device__ __forceinline__ void gather_record(float* r, const float* __restrict_
 }
 // the distance stage needs floats [20, 42) (+ the flag word at 13 for the obtuse-corner bits);
 // depth / colour need [42, REC)
+constexpr int kGatherW0 = 1, kGatherW1 = 4;      // floats [4, 16): inv, flag word, wcull -> barycentrics of the pair
 constexpr int kGatherA0 = 5, kGatherA1 = 11;     // floats [20, 44)
 constexpr int kGatherB0 = 10;                    // floats [40, REC)
 
@@ -781,6 +785,95 @@ __device__ __forceinline__ void for_each_listed_face(const RenderArgs& a, const 
                 body(fn, recs + (long)fn * REC);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase A: which pixels of the tile does each listed face reach?
+// ---------------------------------------------------------------------------------------------
+// The tile's mask row is first unpacked into an ascending face list in LDS.  Then eight faces are examined per
+// step: lane = (face slot, pixel row), the lane gathers its face's first record stage with vector loads -- eight
+// records in flight per step instead of one scalar-load round trip per face, which is what bounded this phase --
+// and walks the eight pixels of its row through the exact box / edge tests (same functions, same operands as a
+// per-pixel evaluation).  The eight row bytes of a face are OR-ed together across its lanes and handed, face by
+// face in ascending order, to body(fn, mask) with mask bit p = pixel lane p (row p >> 3, column p & 7).
+constexpr int kListCap = 128;      // faces unpacked per round (>= 64: one mask word must fit)
+
+__device__ __forceinline__ unsigned quad_or(unsigned v)
+{
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    return v;
+}
+
+template <int REC, typename Body>
+__device__ __forceinline__ void for_each_face_mask(const RenderArgs& a, const TileCtx& t, int* flist, Body body)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int slot = lane >> 3, prow = lane & 7;
+    const float* recs_g = a.records + (long)t.b * a.nf * REC;
+    const unsigned long long* mrow = a.masks + (long)t.tile * a.chunks;
+    const int row_a = t.y0 + prow;
+    const bool row_ok = row_a < a.is;
+    const float yp_a = pixel_coord(a.is - 1 - row_a, a.is);
+
+    int word0 = 0, group0 = 0;                 // next 64-word group to load / base word of the loaded one
+    unsigned long long wv = 0ull, nz = 0ull;   // this lane's word of the loaded group / its non-zero words still to unpack
+    bool done = false;
+    while (!done) {
+        // ---- unpack up to kListCap faces
+        int nlist = 0;
+        for (;;) {
+            if (!nz) {
+                if (word0 >= a.chunks) { done = true; break; }
+                wv = word0 + lane < a.chunks ? mrow[word0 + lane] : 0ull;
+                nz = __ballot(wv != 0ull);
+                group0 = word0;
+                word0 += 64;
+                continue;
+            }
+            const int j = __builtin_ctzll(nz);
+            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), j) << 32)
+                                       | (unsigned)__builtin_amdgcn_readlane((int)wv, j);
+            const int cnt = __popcll(w);
+            if (nlist + cnt > kListCap) break;                       // the word stays in nz for the next round
+            nz &= nz - 1;
+            if ((w >> lane) & 1ull) flist[nlist + __popcll(w & lt)] = (group0 + j) * 64 + lane;
+            nlist += cnt;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- eight faces per step
+        for (int i0 = 0; i0 < nlist; i0 += 8) {
+            const bool has = i0 + slot < nlist;
+            const int fn = flist[has ? i0 + slot : i0];
+            float r[kRecStage1];
+            gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
+            unsigned m8 = 0u;
+            if (has && row_ok) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float xp = pixel_coord(t.x0 + c, a.is);
+                    bool live = t.x0 + c < a.is && inside_box(r, xp, yp_a);
+                    if (live) {
+                        Pair q;
+                        barycentrics(q, r, xp, yp_a);
+                        live = !beyond_an_edge(q, r);
+                    }
+                    m8 |= (live ? 1u : 0u) << c;
+                }
+            }
+            const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
+            const int nslots = min(8, nlist - i0);
+            for (int sl = 0; sl < nslots; sl++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, 8 * sl);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)v, 8 * sl + 4);
+                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                if (!m) continue;
+                body(__builtin_amdgcn_readlane(fn, 8 * sl), m);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1097,7 +1190,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     constexpr int NG = GradSlots<TEXM>::n;       // 9 vertex components, then texture components summed per face in LDS
     constexpr int NT = NG > 9 ? NG - 9 : 1;
     constexpr int WAVES = kThreads / 64;
-    __shared__ __attribute__((aligned(16))) PairRec s_pair[WAVES][64];
+    __shared__ int s_pair[WAVES][64];
+    __shared__ int s_flist[WAVES][kListCap];
     __shared__ __attribute__((aligned(16))) PixIn   s_pix[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
     __shared__ float s_val[WAVES][NG * 65];      // per-pair gradient partials, component-major, rows padded to 65
@@ -1143,19 +1237,19 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         npairs = 0; nfaces = 0; return;
 #endif
         if (lane < npairs) {
-            const PairRec pr = s_pair[wave][lane];
-            const int slot = pr.code >> 8;
-            const PixIn px = s_pix[wave][pr.code & 63];
+            const int code = s_pair[wave][lane];
+            const int slot = code >> 8;
+            const PixIn px = s_pix[wave][code & 63];
             const int fn = s_face[wave][slot].fn;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
             const float* rg = recs_g + (long)fn * REC;
-            r[kRecBits] = rg[kRecBits];
+            gather_record<kGatherW0, kGatherW1>(r, rg);
             gather_record<kGatherA0, kGatherA1>(r, rg);
-            Pair q;
-            q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
             float pxp, pyp;
-            pair_pixel(pxp, pyp, t, pr.code & 63, a.is);
+            pair_pixel(pxp, pyp, t, code & 63, a.is);
+            Pair q;
+            barycentrics(q, r, pxp, pyp);
 
             float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
             float gt[NT];                      // texture partials
@@ -1299,17 +1393,9 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         nfaces = 0;
     };
 
-    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
-        Pair q;
-        unsigned long long m = collect_pairs<REC>(t, rp, q);
-        if (!m) return;
+    for_each_face_mask<REC>(a, t, s_flist[wave], [&](int fn, unsigned long long m) __attribute__((always_inline)) {
         auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
-            if ((mm >> lane) & 1ull) {
-                PairRec pr;
-                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
-                pr.code = (nfaces << 8) | lane;
-                s_pair[wave][npairs + __popcll(mm & lt)] = pr;
-            }
+            if ((mm >> lane) & 1ull) s_pair[wave][npairs + __popcll(mm & lt)] = (nfaces << 8) | lane;
             if (lane == 0) {
                 FaceEnt fe;
                 fe.fn = fn; fe.base = npairs; fe.mask = mm;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kbench with alternative register budgets of the occupancy-capped kernels swapped in (diagnostic)
+# kbench with alternative register budgets of the occupancy-capped forward kernel swapped in (diagnostic)
 cp gendr_amd/libgendr_hip.so /tmp/full.so
-for n in 75 66 76; do cp gpurun_ablate_w$n.so gendr_amd/libgendr_hip.so; echo "fwd/bwd waves=$n"; python tools/kbench.py 2>&1 | grep normal; done
-cp /tmp/full.so gendr_amd/libgendr_hip.so; echo "65 (default)"; python tools/kbench.py | grep normal; python tools/kbench.py | grep normal
+for n in 5; do cp gpurun_ablate_f$n.so gendr_amd/libgendr_hip.so; echo "fwd waves=$n"; python tools/kbench.py 2>&1 | grep -E "normal|offscreen"; done
+cp /tmp/full.so gendr_amd/libgendr_hip.so; echo "6 (default)"; python tools/kbench.py | grep -E "normal|offscreen"
