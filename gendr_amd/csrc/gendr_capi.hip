@@ -274,7 +274,6 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     const Workspace w = workspace_layout(B, nf, T, p);
     float* boxes = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.boxes_off);
     float* recs = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.records_off);
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + w.masks_off);
     int* control = reinterpret_cast<int*>(static_cast<char*>(workspace) + w.control_off);
     // one wavefront per workgroup: 81920 faces are only 1280 wavefronts, spread them over all CUs
     const int blocks = total > 0 ? (int)((total + 63) / 64) : 1;                        // also zeroes the control block
@@ -288,18 +287,12 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
         hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol);
     int e = check_launch();
     if (e != GENDR_OK) return e;
-    // one wavefront per (image, 64x64 super-tile, 64-face chunk)
-    const long waves = (long)B * w.supers_x * w.supers_x * w.chunks;
-    const long bblocks = (waves + (kThreads / 64) - 1) / (kThreads / 64);
-    if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
-    if (bblocks > 0)
-        hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kThreads), 0, s, boxes, masks,
-                       B, nf, p->image_size, w.tiles_x, w.chunks, w.supers_x, p->cull);
-    e = check_launch();
-    if (e != GENDR_OK) return e;
+    // one workgroup per (image, 64x64 super-tile): tile masks and the tile queues
     RenderArgs a;
     fill_args(a, workspace, textures, B, nf, T, p);
-    hipLaunchKernelGGL(tile_list_kernel, dim3((unsigned)(((long)a.total_tiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a);
+    const long bblocks = (long)B * w.supers_x * w.supers_x;
+    if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
+    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kBinThreads), 0, s, boxes, a, w.supers_x, p->cull);
     return check_launch();
 }
 

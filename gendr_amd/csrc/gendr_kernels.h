@@ -40,6 +40,10 @@
 #define GENDR_BWD_WAVES 5
 #endif
 
+#ifndef GENDR_BIN_THREADS
+#define GENDR_BIN_THREADS 512
+#endif
+
 #ifndef GENDR_SPLIT_MIN
 #define GENDR_SPLIT_MIN 8
 #endif
@@ -385,53 +389,96 @@ __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry
 }
 
 // ---------------------------------------------------------------------------------------------
-// binning: masks[b][tile][chunk], bit f of chunk c = face 64c+f of image b may touch the 8x8 tile.
-// One wavefront takes 64 faces (lane = face, coalesced box load) and a block of 8x8 tiles (a 64x64 pixel
-// super-tile, lane = tile as well).  A ballot finds the few faces whose box meets the super-tile at all; for
-// each of them the box is broadcast with v_readlane and every tile lane sets its bit.  Lane t ends up with the
-// mask word of tile t and the 64 words leave in one store.
+// binning: masks[b][tile][chunk], bit f of chunk c = face 64c+f of image b may touch the 8x8 tile; and the tile
+// queues the render kernels walk.
+// One workgroup takes a block of 8x8 tiles (a 64x64 pixel super-tile) of one image; its wavefronts share the face
+// chunks.  For a chunk, lane = face (coalesced box load) and lane = tile as well: a ballot finds the few faces whose
+// box meets the super-tile at all; for each of them the box is broadcast with v_readlane and every tile lane sets
+// its bit.  The words go to LDS, from where the mask rows leave in runs of 8 tiles x chunks words (the rows of 8
+// horizontally adjacent tiles are contiguous in HBM).  Once all chunks are done the first wavefront knows, per tile,
+// whether its row is empty and appends the tile to its queue: listed tiles grow the queue from the front, the others
+// -- the background, three quarters of the headline scene -- from the back of the queue's slots (the forward kernel
+// writes their pixels in a store-only loop, backward never looks at them).  Two atomics per workgroup.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void bin_faces_kernel(
-    const float* __restrict__ boxes, unsigned long long* __restrict__ masks,
-    int B, int nf, int is, int tiles_x, int chunks, int supers_x, int cull)
+constexpr int kBinThreads = GENDR_BIN_THREADS, kBinWaves = kBinThreads / 64;
+constexpr int kBinGroup = 32;      // chunks staged in LDS per round
+
+__global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
 {
-    const int lane = threadIdx.x & 63;
-    const long wid = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    const long per_image = (long)supers_x * supers_x * chunks;
-    if (wid >= per_image * B) return;
-    const int b = (int)(wid / per_image);
-    long rem = wid - (long)b * per_image;
-    const int sup = (int)(rem / chunks), c = (int)(rem - (long)sup * chunks);
+    __shared__ unsigned long long s_words[64][kBinGroup + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int is = a.is, tiles_x = a.tiles_x, chunks = a.chunks;
+    const int per_image = supers_x * supers_x;
+    const int b = blockIdx.x / per_image;
+    const int sup = blockIdx.x - b * per_image;
     const int sy = sup / supers_x, sx = sup - sy * supers_x;
 
-    const int fi = c * 64 + lane;
-    const bool have = fi < nf;
-    float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
-    if (have) box = reinterpret_cast<const float4*>(boxes)[(long)b * nf + fi];
-
-    // lane t also owns tile t of the super-tile: its rectangle and, at the end, its mask word
+    // lane t owns tile t of the super-tile: its rectangle and, at the end, its mask words
     const int ty_l = sy * 8 + (lane >> 3), tx_l = sx * 8 + (lane & 7);
     const bool tile_ok = ty_l < tiles_x && tx_l < tiles_x;
     const float rx_lo = pixel_coord(tx_l * 8, is), rx_hi = pixel_coord(min(tx_l * 8 + 7, is - 1), is);
     const float ry_hi = pixel_coord(is - 1 - ty_l * 8, is), ry_lo = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is);
-    unsigned long long mine = 0ull;
-
-    // faces of the chunk whose box meets the super-tile at all (usually a handful of the 64)
     const float sx_lo = pixel_coord(sx * 64, is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is);
     const float sy_hi = pixel_coord(is - 1 - sy * 64, is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is);
-    unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
-    while (cand) {
-        const int f = __builtin_ctzll(cand);
-        cand &= cand - 1;
-        float4 fb;                                                       // face f's box, broadcast to every tile lane
-        fb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.x), f));
-        fb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.y), f));
-        fb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.z), f));
-        fb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.w), f));
-        if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << f;
+    const long tile_base = (long)b * a.tiles_per_image;
+    unsigned long long seen = 0ull;                                          // first wavefront: OR of this tile's words
+
+    for (int c0 = 0; c0 < chunks; c0 += kBinGroup) {
+        const int ng = min(kBinGroup, chunks - c0);
+        for (int ci = wave; ci < ng; ci += kBinWaves) {
+            const int fi = (c0 + ci) * 64 + lane;
+            const bool have = fi < a.nf;
+            float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
+            if (have) box = reinterpret_cast<const float4*>(boxes)[(long)b * a.nf + fi];
+            unsigned long long mine = 0ull;
+            // faces of the chunk whose box meets the super-tile at all (usually a handful of the 64)
+            unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
+            while (cand) {
+                const int f = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                float4 fb;                                                       // face f's box, broadcast to every tile lane
+                fb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.x), f));
+                fb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.y), f));
+                fb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.z), f));
+                fb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.w), f));
+                if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << f;
+            }
+            s_words[lane][ci] = mine;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 64 * ng; idx += kBinThreads) {         // consecutive threads: consecutive words of a row
+            const int tl = idx / ng, ci = idx - tl * ng;
+            const int ty = sy * 8 + (tl >> 3), tx = sx * 8 + (tl & 7);
+            if (ty < tiles_x && tx < tiles_x)
+                const_cast<unsigned long long*>(a.masks)[(tile_base + (long)ty * tiles_x + tx) * chunks + c0 + ci] = s_words[tl][ci];
+        }
+        if (wave == 0)
+            for (int ci = 0; ci < ng; ci++) seen |= s_words[lane][ci];
+        __syncthreads();
     }
-    if (tile_ok)
-        masks[((long)b * tiles_x * tiles_x + (long)ty_l * tiles_x + tx_l) * chunks + c] = mine;
+    if (wave != 0) return;
+
+    // tile queues.  Usually the 64 tiles belong to one queue; small batches of small images put several into one wave
+    const long g = tile_base + (long)ty_l * tiles_x + tx_l;
+    const int xq = tile_ok ? queue_of_tile(g, a.total_tiles) : -1;
+    unsigned long long todo = __ballot(tile_ok);
+    while (todo) {
+        const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
+        const unsigned long long mine = __ballot(xq == x);
+        todo &= ~mine;
+        const unsigned long long listed = __ballot(xq == x && seen != 0ull);
+        const unsigned long long empty = mine & ~listed;
+        int base_l = 0, base_e = 0;
+        if (lane == 0) {
+            if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
+            if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
+        }
+        base_l = __builtin_amdgcn_readfirstlane(base_l);
+        base_e = __builtin_amdgcn_readfirstlane(base_e);
+        if ((listed >> lane) & 1ull) a.tile_list[queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt)] = (int)g;
+        if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -874,68 +921,6 @@ __device__ __forceinline__ void for_each_face_mask(const RenderArgs& a, const Ti
             }
         }
         __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// tile lists + background
-// ---------------------------------------------------------------------------------------------
-// One lane per tile, one wavefront per 64 consecutive tiles of an image.  Tiles whose mask row lists at least one
-// face are appended to their image's queue (one atomic per wavefront); the render loops only ever see those.
-// Tiles that list none -- the background, three quarters of the headline scene -- are collected at the back of the
-// queue's slots; the forward kernel writes their pixels in a store-only loop, backward never looks at them.
-__global__ __launch_bounds__(kThreads) void tile_list_kernel(const RenderArgs a)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const long g0 = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) << 6;     // first global tile id of this wave
-    if (g0 >= a.total_tiles) return;
-    const long g = g0 + lane;
-    const bool valid = g < a.total_tiles;
-    // The 64 mask rows of this wavefront are one contiguous block of 64 * chunks words: read it with coalesced
-    // loads (lane = word), ballot "word != 0", and let lane r test the bits of its own row [r*chunks, (r+1)*chunks).
-    bool any = false;
-    {
-        const long words_left = (a.total_tiles - g0) * a.chunks;              // rows past the end are not read
-        const unsigned long long* blk = a.masks + g0 * a.chunks;
-        const int lo = lane * a.chunks, hi = lo + a.chunks;
-        for (int i0 = 0; i0 < a.chunks; i0 += 8) {                             // 8 loads in flight, then their ballots
-            unsigned long long v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int w = (i0 + u) * 64 + lane;
-                v[u] = (i0 + u < a.chunks && w < words_left) ? blk[w] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = i0 + u;
-                const unsigned long long nz = __ballot(v[u] != 0ull);
-                const int s0 = max(lo, i * 64) - i * 64, s1 = min(hi, i * 64 + 64) - i * 64;
-                if (s0 < s1) {
-                    const unsigned long long span = (s1 - s0 == 64 ? ~0ull : ((1ull << (s1 - s0)) - 1ull)) << s0;
-                    any = any || (nz & span) != 0ull;
-                }
-            }
-        }
-    }
-    // usually the 64 tiles belong to one queue; small batches of small images put several queues into one wave
-    const int xq = valid ? queue_of_tile(g, a.total_tiles) : -1;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
-        const unsigned long long mine = __ballot(xq == x);
-        todo &= ~mine;
-        const unsigned long long listed = __ballot(xq == x && any);
-        const unsigned long long empty = mine & ~listed;
-        int base_l = 0, base_e = 0;
-        if (lane == 0) {
-            if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
-            if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
-        }
-        base_l = __builtin_amdgcn_readfirstlane(base_l);
-        base_e = __builtin_amdgcn_readfirstlane(base_e);
-        if ((listed >> lane) & 1ull) a.tile_list[queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt)] = (int)g;
-        if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
     }
 }
 
