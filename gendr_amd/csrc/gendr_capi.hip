@@ -29,14 +29,16 @@ typedef void (*render_kernel_t)(const RenderArgs);
 // scripts get their own kernel (only their own CDF / t-conorm branch is compiled in); everything else runs
 // the runtime-dispatch kernel of its texture mode, which carries all 18 x 10 branches.
 struct KernelKey { int dist, alpha, rgb, sq, texm; };
-struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; };
+struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd, bwd_wide; };   // bwd_wide: eight-faces-per-step phase A
 
 #define GENDR_SPECIALISE(D, A, RGB, SQ, TEXM) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM, 0>, \
+      render_backward_kernel<D, A, RGB, SQ, TEXM, 1> }
 
 // same, with the register budget capped for 6 (forward) / 5 (backward) waves per SIMD
 #define GENDR_SPECIALISE_OCC(D, A, RGB, SQ, TEXM) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM, 0>, \
+      render_backward_kernel_w5<D, A, RGB, SQ, TEXM, 1> }
 
 const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 1, 0, kTexSurface1),   // C2 headline; library defaults
@@ -48,16 +50,22 @@ const KernelEntry kSpecialised[] = {
 };
 
 const KernelEntry kGeneric[3] = {
-    { {-1, -1, -1, -1, kTexSurface1}, render_forward_kernel<-1, -1, -1, -1, kTexSurface1>, render_backward_kernel<-1, -1, -1, -1, kTexSurface1> },
-    { {-1, -1, -1, -1, kTexVertex},   render_forward_kernel<-1, -1, -1, -1, kTexVertex>,   render_backward_kernel<-1, -1, -1, -1, kTexVertex> },
-    { {-1, -1, -1, -1, kTexSurfaceN}, render_forward_kernel<-1, -1, -1, -1, kTexSurfaceN>, render_backward_kernel<-1, -1, -1, -1, kTexSurfaceN> },
+    { {-1, -1, -1, -1, kTexSurface1}, render_forward_kernel<-1, -1, -1, -1, kTexSurface1>, render_backward_kernel<-1, -1, -1, -1, kTexSurface1, 0>,
+      render_backward_kernel<-1, -1, -1, -1, kTexSurface1, 1> },
+    { {-1, -1, -1, -1, kTexVertex},   render_forward_kernel<-1, -1, -1, -1, kTexVertex>,   render_backward_kernel<-1, -1, -1, -1, kTexVertex, 0>,
+      render_backward_kernel<-1, -1, -1, -1, kTexVertex, 1> },
+    { {-1, -1, -1, -1, kTexSurfaceN}, render_forward_kernel<-1, -1, -1, -1, kTexSurfaceN>, render_backward_kernel<-1, -1, -1, -1, kTexSurfaceN, 0>,
+      render_backward_kernel<-1, -1, -1, -1, kTexSurfaceN, 1> },
 };
 
 // light runtime-dispatch kernels: 13 light distributions x 5 light alpha aggregators, any RGB / squared flag
 const KernelEntry kGenericLight[3] = {
-    { {-2, -2, -1, -1, kTexSurface1}, render_forward_kernel<-2, -2, -1, -1, kTexSurface1>, render_backward_kernel<-2, -2, -1, -1, kTexSurface1> },
-    { {-2, -2, -1, -1, kTexVertex},   render_forward_kernel<-2, -2, -1, -1, kTexVertex>,   render_backward_kernel<-2, -2, -1, -1, kTexVertex> },
-    { {-2, -2, -1, -1, kTexSurfaceN}, render_forward_kernel<-2, -2, -1, -1, kTexSurfaceN>, render_backward_kernel<-2, -2, -1, -1, kTexSurfaceN> },
+    { {-2, -2, -1, -1, kTexSurface1}, render_forward_kernel<-2, -2, -1, -1, kTexSurface1>, render_backward_kernel<-2, -2, -1, -1, kTexSurface1, 0>,
+      render_backward_kernel<-2, -2, -1, -1, kTexSurface1, 1> },
+    { {-2, -2, -1, -1, kTexVertex},   render_forward_kernel<-2, -2, -1, -1, kTexVertex>,   render_backward_kernel<-2, -2, -1, -1, kTexVertex, 0>,
+      render_backward_kernel<-2, -2, -1, -1, kTexVertex, 1> },
+    { {-2, -2, -1, -1, kTexSurfaceN}, render_forward_kernel<-2, -2, -1, -1, kTexSurfaceN>, render_backward_kernel<-2, -2, -1, -1, kTexSurfaceN, 0>,
+      render_backward_kernel<-2, -2, -1, -1, kTexSurfaceN, 1> },
 };
 
 const KernelEntry& pick_kernel(const gendr_params* p, int texm)
@@ -337,7 +345,11 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.grad_textures = grad_textures;
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
-    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    // Phase A of backward examines eight faces side by side when tiles list many faces, i.e. when faces are small
+    // next to an 8x8 tile; the host only knows image size and face count, which is a fair proxy: below 400 pixels of
+    // image per face (C2: 51, C4: 205, C5 at 2048^2: 3277) the wide walk is used.
+    const bool wide = (long)p->image_size * p->image_size < 400L * nf;
+    hipLaunchKernelGGL(wide ? k.bwd_wide : k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

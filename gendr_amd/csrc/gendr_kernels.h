@@ -1168,7 +1168,10 @@ struct PixIn {             // 40 bytes: per-pixel inputs of the backward pass, k
     float g[4], out[4], ssum, smax;
 };
 
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+// WIDE selects phase A: 1 = eight faces per step (for_each_face_mask), 0 = one face per step with scalar-loaded records
+// (for_each_listed_face).  The wide walk wins when tiles list many faces (small faces relative to a tile: the
+// headline scene lists 17 per tile on average); with one to three faces per tile -- large images -- it mostly idles.
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
 __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 {
     constexpr int REC = record_floats(TEXM);
@@ -1176,7 +1179,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     constexpr int NT = NG > 9 ? NG - 9 : 1;
     constexpr int WAVES = kThreads / 64;
     __shared__ int s_pair[WAVES][64];
-    __shared__ int s_flist[WAVES][kListCap];
+    __shared__ int s_flist[WAVES][WIDE ? kListCap : 1];
     __shared__ __attribute__((aligned(16))) PixIn   s_pix[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
     __shared__ float s_val[WAVES][NG * 65];      // per-pair gradient partials, component-major, rows padded to 65
@@ -1378,7 +1381,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         nfaces = 0;
     };
 
-    for_each_face_mask<REC>(a, t, s_flist[wave], [&](int fn, unsigned long long m) __attribute__((always_inline)) {
+    auto take_face = [&](int fn, unsigned long long m) __attribute__((always_inline)) {
         auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
             if ((mm >> lane) & 1ull) s_pair[wave][npairs + __popcll(mm & lt)] = (nfaces << 8) | lane;
             if (lane == 0) {
@@ -1399,23 +1402,32 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             run_batch();
         }
         emit(m);
-    });
+    };
+    if constexpr (WIDE) {
+        for_each_face_mask<REC>(a, t, s_flist[wave], take_face);
+    } else {
+        for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
+            Pair q;
+            const unsigned long long m = collect_pairs<REC>(t, rp, q);
+            if (m) take_face(fn, m);
+        });
+    }
     if (npairs > 0) run_batch();
     __builtin_amdgcn_wave_barrier();
     }   // tile loop
 }
 
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
 __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderArgs a)
 {
-    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
 }
 
 // register budget capped for 5 waves per SIMD (96 VGPRs), see render_forward_kernel_w6
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BWD_WAVES))) void render_backward_kernel_w5(const RenderArgs a)
 {
-    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
 }
 
 }  // namespace gendr
