@@ -205,15 +205,17 @@ def main():
     if rank == 0:
         P = isz * isz
         fwd_b, bwd_b = algorithmic_bytes(P, nf, T)
-        dom = 'render_backward_kernel' if bwd_ms >= fwd_ms else 'face_setup_kernel+render_forward_kernel'
-        dom_bytes = (bwd_b if bwd_ms >= fwd_ms else fwd_b) * B
-        dom_ms = max(bwd_ms, fwd_ms)
+        # The longest single kernel is the backward render kernel (the forward phase is three launches: face setup,
+        # binning, forward render); the events around the backward native call bracket exactly that one kernel.
+        dom = 'render_backward_kernel'
+        dom_bytes = bwd_b * B
+        dom_ms = bwd_ms
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.config)
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch', {}).get(dom.split('+')[-1])
+                traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch', {}).get(dom)
             except Exception:
                 traffic = None
         out = {
