@@ -8,20 +8,21 @@
 //   backward_render_cuda_kernel    :866-1065 ->  render_backward_kernel
 //
 // Design (DESIGN.md has the long form and the measurements behind it):
-//   * one wavefront = one 8x8 pixel tile, lane = pixel.  The per-pixel alpha fold and online softmax keep
-//     the reference's ascending-face order without any cross-lane combination in forward;
-//   * exact tile culling: the face-setup kernel writes, per face, a conservative box outside of which the
-//     reference itself would skip the pair (kernel.cu:747,769,784); the binning kernel ballots those boxes
-//     against every tile rectangle and leaves one bit per (tile, face) in HBM -- ascending face order for
-//     free, no atomics, shared by forward and backward;
-//   * everything a face contributes to the inner loop is wave-uniform, so it lives in SGPRs: the tile's
-//     mask words and the 176-byte face records are fetched with scalar loads (constant address space)
-//     straight out of L2 / the scalar cache.  No LDS, no barriers, 8 waves per SIMD hide the latency;
-//   * inside the loop every lane still applies the reference's own three skip tests, so culling only
-//     removes pairs that contribute exactly nothing;
-//   * backward recomputes the pair (as the reference does), reduces the 9 (+3 / +9) partials over the
-//     wavefront with DPP adds and issues one hardware fp32 atomic per (tile, face, component) instead of
-//     12..84 per (pixel, face).
+//   * one wavefront = one 8x8 pixel tile.  Exact tile culling: the face-setup kernel writes, per face, a conservative
+//     box outside of which the reference itself would skip the pair (kernel.cu:747,769,784); the binning kernel
+//     tests those boxes against every tile rectangle, leaves one bit per (tile, face) in HBM -- ascending face order
+//     for free, shared by forward and backward -- and queues the tiles that list anything (8 queues, one per XCD);
+//   * the render kernels walk those queues.  Per tile: phase A finds the (pixel, face) pairs that survive the exact
+//     per-pixel tests (forward: lane = pixel, face record in SGPRs via scalar loads; backward: eight faces per step,
+//     lane = (face, pixel row), records by vector gathers) and appends them to a wave-private LDS list;
+//     phase B runs dense -- lane = pair -- over batches of 64 pairs: distance, CDF, depth, colour (+ gradients);
+//     phase C (forward) folds the results per pixel in ascending face order, so the alpha fold and the online
+//     softmax keep the reference's order without any cross-lane combination; backward instead sums each face's
+//     partials over its pairs from a padded LDS matrix and issues one hardware fp32 atomic per (batch, face,
+//     component) instead of 12..84 per (pixel, face);
+//   * inside the loop every pair still passes the reference's own three skip tests, so culling only removes pairs
+//     that contribute exactly nothing;
+//   * everything is wave-local: no workgroup barriers in the render kernels, 4 independent wave-tiles per workgroup.
 //
 // No MFMA: there is no dense contraction in this path.  Compiled with -ffp-contract=off.
 #pragma once
@@ -370,15 +371,6 @@ __global__ __launch_bounds__(kThreads) void face_info_kernel(const float* __rest
 __device__ __forceinline__ float pixel_coord(int idx, int is)
 {
     return div_by((float)(2 * idx + 1 - is), 1. / (double)is);   // 1/is folds to a wave-uniform constant
-}
-
-// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8).  Remap so that each XCD walks a
-// contiguous range of tiles: all tiles of one image then hit the same 4 MiB L2 for that image's face
-// records and masks.  Affects speed only.
-__device__ __forceinline__ int xcd_remap(int b, int n)
-{
-    const int xcd = b & 7, idx = b >> 3, per = n >> 3, rem = n & 7;
-    return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
 // box = (xlo, xhi, ylo, yhi).  A rectangle of pixel centres misses the box iff every centre fails the
