@@ -41,6 +41,10 @@
 #define GENDR_BWD_WAVES 5
 #endif
 
+#ifndef GENDR_BIN_LOOP_MAX
+#define GENDR_BIN_LOOP_MAX 16
+#endif
+
 #ifndef GENDR_BIN_THREADS
 #define GENDR_BIN_THREADS 512
 #endif
@@ -394,6 +398,7 @@ __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry
 // ---------------------------------------------------------------------------------------------
 constexpr int kBinThreads = GENDR_BIN_THREADS, kBinWaves = kBinThreads / 64;
 constexpr int kBinGroup = 32;      // chunks staged in LDS per round
+constexpr int kBinLoopMax = GENDR_BIN_LOOP_MAX;   // up to this many candidate faces of a chunk are broadcast one by one
 
 __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
 {
@@ -418,23 +423,59 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
 
     for (int c0 = 0; c0 < chunks; c0 += kBinGroup) {
         const int ng = min(kBinGroup, chunks - c0);
-        for (int ci = wave; ci < ng; ci += kBinWaves) {
+        // this wavefront's chunks of the round: all box loads first (one memory round trip instead of one per chunk)
+        constexpr int kPerWave = (kBinGroup + kBinWaves - 1) / kBinWaves;
+        float4 boxes_w[kPerWave];
+#pragma unroll
+        for (int u = 0; u < kPerWave; u++) {
+            const int ci = wave + u * kBinWaves;
             const int fi = (c0 + ci) * 64 + lane;
-            const bool have = fi < a.nf;
-            float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
-            if (have) box = reinterpret_cast<const float4*>(boxes)[(long)b * a.nf + fi];
+            boxes_w[u] = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
+            if (ci < ng && fi < a.nf) boxes_w[u] = reinterpret_cast<const float4*>(boxes)[(long)b * a.nf + fi];
+        }
+#pragma unroll
+        for (int u = 0; u < kPerWave; u++) {
+            const int ci = wave + u * kBinWaves;
+            if (ci >= ng) break;
+            const float4 box = boxes_w[u];
+            const bool have = (c0 + ci) * 64 + lane < a.nf;
             unsigned long long mine = 0ull;
-            // faces of the chunk whose box meets the super-tile at all (usually a handful of the 64)
+            // faces of the chunk whose box meets the super-tile at all
             unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
-            while (cand) {
-                const int f = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                float4 fb;                                                       // face f's box, broadcast to every tile lane
-                fb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.x), f));
-                fb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.y), f));
-                fb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.z), f));
-                fb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.w), f));
-                if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << f;
+            if (__popcll(cand) <= kBinLoopMax) {
+                // a handful: broadcast each box, every tile lane sets its bit
+                while (cand) {
+                    const int f = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    float4 fb;
+                    fb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.x), f));
+                    fb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.y), f));
+                    fb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.z), f));
+                    fb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.w), f));
+                    if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << f;
+                }
+            } else {
+                // many (the super-tiles under the object): the same predicate is separable, so every face lane marks
+                // the tile columns and tile rows its box meets and one ballot per tile collects that tile's word
+                unsigned mx = 0u, my = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    // column k's x-range is held by lane k (row 0), row k's y-range by lane 8k (column 0)
+                    const float cx_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_lo), k));
+                    const float cx_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_hi), k));
+                    const float cy_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_lo), 8 * k));
+                    const float cy_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_hi), 8 * k));
+                    const bool hx = cull ? !(cx_lo > box.y || cx_hi < box.x) : true;
+                    const bool hy = cull ? !(cy_lo > box.w || cy_hi < box.z) : true;
+                    mx |= (hx ? 1u : 0u) << k;
+                    my |= (hy ? 1u : 0u) << k;
+                }
+                if (!((cand >> lane) & 1ull)) mx = 0u;              // also drops lanes without a face
+#pragma unroll
+                for (int tl = 0; tl < 64; tl++) {
+                    const unsigned long long word = __ballot(((mx >> (tl & 7)) & 1u) && ((my >> (tl >> 3)) & 1u));
+                    if (lane == tl) mine = word;
+                }
             }
             s_words[lane][ci] = mine;
         }
