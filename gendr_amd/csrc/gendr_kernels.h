@@ -965,7 +965,8 @@ struct FwdRes {            // 32 bytes: what phase C needs from a pair
     float z;               // zp (hard RGB) or zn (softmax)
     float c0, c1, c2;      // sampled colour
     int   flags;
-    int   pad0, pad1;
+    int   fn;              // face index (hard RGB keeps the nearest face's, kernel.cu:819)
+    int   pad1;
 };
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
@@ -1006,11 +1007,12 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
     int npairs = 0, nfaces = 0;
+    unsigned long long my_pairs = 0ull;        // bit i: pair i of the open batch belongs to this lane's pixel
 
     auto run_batch = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
 #if GENDR_ABLATE == 1
-        alpha += (float)npairs; npairs = 0; nfaces = 0; return;
+        alpha += (float)npairs; npairs = 0; nfaces = 0; my_pairs = 0ull; return;
 #endif
         // ---- phase B: one pair per lane
         if (lane < npairs) {
@@ -1025,7 +1027,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
             const float pxp = pr.xp, pyp = pr.yp;
             FwdRes res;
-            res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.pad0 = res.pad1 = 0;
+            res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fn = fn; res.pad1 = 0;
             if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) {
                 gather_record<kGatherB0, REC / 4>(r, rg);
                 res.flags = kFlagContrib;
@@ -1050,17 +1052,12 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         }
         __builtin_amdgcn_wave_barrier();
 #if GENDR_ABLATE == 2
-        alpha += s_res[wave][lane].frag; npairs = 0; nfaces = 0; return;
+        alpha += s_res[wave][lane].frag; npairs = 0; nfaces = 0; my_pairs = 0ull; return;
 #endif
-        // ---- phase C: per pixel, faces in ascending order
-        for (int s = 0; s < nfaces; s++) {
-            const FaceEnt fe = s_face[wave][s];
-            const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(fe.mask >> 32)) << 32)
-                                       | (unsigned)__builtin_amdgcn_readfirstlane((int)fe.mask);
-            const int base = __builtin_amdgcn_readfirstlane(fe.base);
-            const int fn = __builtin_amdgcn_readfirstlane(fe.fn);
-            if (!((m >> lane) & 1ull)) continue;
-            const FwdRes res = s_res[wave][base + __popcll(m & lt)];
+        // ---- phase C: every pixel folds its own pairs; their list positions ascend with the face index
+        for (unsigned long long todo = my_pairs; todo; todo &= todo - 1) {
+            const FwdRes res = s_res[wave][__builtin_ctzll(todo)];
+            const int fn = res.fn;
             if (!(res.flags & kFlagContrib)) continue;
             // alpha, kernel.cu:791-803
             if (alpha_func == kAlphaHard) {
@@ -1095,6 +1092,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         }
         npairs = 0;
         nfaces = 0;
+        my_pairs = 0ull;
     };
 
     for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
@@ -1106,7 +1104,9 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
                 PairRecXY pr;
                 pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
                 pr.code = (nfaces << 8) | lane; pr.xp = t.xp; pr.yp = t.yp; pr.pad0 = 0; pr.pad1 = 0;
-                s_pair[wave][npairs + __popcll(mm & lt)] = pr;
+                const int at = npairs + __popcll(mm & lt);
+                s_pair[wave][at] = pr;
+                my_pairs |= 1ull << at;
             }
             if (lane == 0) {
                 FaceEnt fe;
