@@ -41,10 +41,14 @@ __global__ __launch_bounds__(kProjThreads) void project_faces_kernel(
     const int b = (int)(i / per_item);
     const long fk = i - (long)b * per_item;
     const int idx = face_index[(index_batched ? (long)b * per_item : 0) + fk];
+    float* o = face_vertices + i * 3;
+    if ((unsigned)idx >= (unsigned)nv) {                   // never read outside the vertex tensor: a bad index shows as NaN
+        o[0] = o[1] = o[2] = __int_as_float(0x7fc00000);
+        return;
+    }
     const float* v = vertices + ((long)b * nv + idx) * 3;
     float d0, d1, d2, c0, c1, c2, ox, oy, oz;
     project_point(v, camera + (long)b * 12, perspective, ws, d0, d1, d2, c0, c1, c2, ox, oy, oz);
-    float* o = face_vertices + i * 3;
     o[0] = ox; o[1] = oy; o[2] = oz;
 }
 
@@ -72,8 +76,8 @@ __global__ __launch_bounds__(kProjThreads) void project_faces_backward_kernel(
     const bool live = fk < per_item;
     const float* cam = camera + (long)b * 12;
     float gd0 = 0.f, gd1 = 0.f, gd2 = 0.f, gR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (live) {
-        const int idx = face_index[(index_batched ? (long)b * per_item : 0) + fk];
+    const int idx = live ? face_index[(index_batched ? (long)b * per_item : 0) + fk] : 0;
+    if (live && (unsigned)idx < (unsigned)nv) {            // bad indices contribute nothing (forward already shows NaN)
         const float* v = vertices + ((long)b * nv + idx) * 3;
         float d0, d1, d2, c0, c1, c2, ox, oy, oz;
         project_point(v, cam, perspective, ws, d0, d1, d2, c0, c1, c2, ox, oy, oz);

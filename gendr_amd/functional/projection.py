@@ -28,7 +28,8 @@ _validated = {}
 
 
 def _check_indices(faces, nv):
-    """Range check of the face indices (a host sync), once per index tensor version."""
+    """Range check of the face indices (a host sync), once per index tensor version.  Error reporting only: the
+    kernels never read outside the vertex tensor (an out-of-range index yields NaN vertices and no gradient)."""
     key = (faces.data_ptr(), faces._version, tuple(faces.shape), nv)
     if _validated.get('key') == key:
         return
