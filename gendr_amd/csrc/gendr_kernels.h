@@ -780,21 +780,22 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 //
 // Measured on the headline scene: a face touches only ~14 of a tile's 64 pixels, so evaluating "one face per
 // loop iteration, lane = pixel" leaves ~78 % of the lanes idle in the expensive stages.  Instead:
-//   phase A  (lane = pixel, one iteration per listed face, cheap): box test, barycentrics, edge reject; the
-//            surviving (pixel, face) pairs are appended -- in ascending (face, pixel) order -- to a
-//            wavefront-private list in LDS, together with the face's ballot mask;
+//   phase A  (cheap): box test, barycentrics, edge reject for every pixel of the tile against every listed face --
+//            forward: lane = pixel, one face per iteration (collect_pairs); backward: lane = (face, pixel row), eight
+//            faces per step (for_each_face_mask).  The surviving (pixel, face) pairs are appended -- in ascending
+//            (face, pixel) order -- to a wavefront-private list in LDS, together with the face's ballot mask;
 //   phase B  (lane = pair, dense): every lane fetches ITS pair's face record from L2 and runs the distance,
 //            CDF, clip/depth and colour stages; results go back to LDS;
-//   phase C  forward : lane = pixel again; faces of the batch are walked in ascending order and each pixel folds
-//                      its own pair's result (t-conorm fold, z-buffer / online softmax) -- the reference's order;
-//            backward: nothing sequential is left; gradients are summed per face with LDS atomics and leave the
-//                      CU as one hardware fp32 atomic per (tile batch, face, component).
+//   phase C  forward : lane = pixel again; each pixel folds the results of its own pairs in list order, i.e. in
+//                      ascending face order (t-conorm fold, z-buffer / online softmax) -- the reference's order;
+//            backward: nothing sequential is left; one lane per (face, component) sums the partials of the face's
+//                      pairs from LDS and issues one hardware fp32 atomic per (tile batch, face, component).
 // Everything is wavefront-local: no barriers.
 // ---------------------------------------------------------------------------------------------
-// A pair in the batch list is one int: (face slot in the batch << 8) | pixel lane.  Its barycentrics are computed in
-// phase B from the gathered record (the same expressions on the same operands as everywhere else).
-// Forward keeps the scalar-load phase A below (collect_pairs): its phase B has no registers to spare for the
-// barycentrics, so they travel with the pair, as does the pixel centre.
+// Backward: a pair in the batch list is one int, (face slot in the batch << 8) | pixel lane; its barycentrics are
+// computed in phase B from the gathered record (the same expressions on the same operands as everywhere else).
+// Forward: its phase B has no registers to spare for that, so the barycentrics travel with the pair, as does the
+// pixel centre.
 struct PairRecXY {         // 32 bytes: forward keeps the pixel centre with the pair (its LDS budget allows it,
     float w0, w1, w2;      // and recomputing it costs the forward kernel an occupancy step in registers)
     int   code;
