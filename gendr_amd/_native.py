@@ -40,13 +40,28 @@ class GendrParams(ctypes.Structure):
     ]
 
 
+MAX_DIRECTIONAL = 4
+
+
+class GendrLightParams(ctypes.Structure):
+    """``gendr_light_params`` of include/gendr_hip.h."""
+    _fields_ = [
+        ("ambient_intensity", ctypes.c_float),
+        ("ambient_color", ctypes.c_float * 3),
+        ("n_directional", ctypes.c_int),
+        ("intensity", ctypes.c_float * MAX_DIRECTIONAL),
+        ("color", (ctypes.c_float * 3) * MAX_DIRECTIONAL),
+        ("direction", (ctypes.c_float * 3) * MAX_DIRECTIONAL),
+    ]
+
+
 EXPORTS = (
     "gendr_abi_version", "gendr_params_size", "gendr_error_string", "gendr_workspace_bytes", "gendr_validate",
     "gendr_face_setup", "gendr_forward", "gendr_backward", "gendr_face_info",
     "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
     "gendr_cull_radius", "gendr_project_faces", "gendr_project_faces_backward",
     "gendr_camera_rotation", "gendr_camera_rotation_backward",
-    "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
+    "gendr_light_faces", "gendr_light_faces_backward", "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
 )
 
 _lib = None
@@ -93,6 +108,10 @@ def lib():
     for name in ("gendr_t_conorm_forward", "gendr_t_conorm_backward"):
         getattr(L, name).restype = f
         getattr(L, name).argtypes = [i, f, f, i, f]
+    L.gendr_light_faces.restype = i
+    L.gendr_light_faces.argtypes = [vp, vp, vp, vp, i, i, i, i, i, ctypes.POINTER(GendrLightParams), vp]
+    L.gendr_light_faces_backward.restype = i
+    L.gendr_light_faces_backward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, ctypes.POINTER(GendrLightParams), vp]
     L.gendr_load_textures.restype = i
     L.gendr_load_textures.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
     L.gendr_create_texture_image.restype = i

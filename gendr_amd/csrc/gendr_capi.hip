@@ -12,6 +12,7 @@
 #include "gendr_project.h"
 #include "gendr_voxel.h"
 #include "gendr_texture.h"
+#include "gendr_light.h"
 
 using namespace gendr;
 
@@ -406,6 +407,36 @@ int gendr_voxelize(const float* faces, int* voxels, void* workspace, int B, int 
                            voxels, (u64*)nullptr, vs, W);
     else
         hipLaunchKernelGGL(voxel_fill_kernel<false>, dim3(B), dim3(kVoxFillThreads), 0, st, voxels, (u64*)workspace, vs, W);
+    return check_launch();
+}
+
+int gendr_light_faces(const float* vertices, const int* face_index, const float* textures, float* out,
+                      int B, int nv, int nf, int T, int index_batched, const gendr_light_params* lp, void* stream)
+{
+    if (B < 0 || nv < 0 || nf < 0 || T < 0) return GENDR_E_SHAPE;
+    if (!lp) return GENDR_E_NULL;
+    if (lp->n_directional < 0 || lp->n_directional > GENDR_MAX_DIRECTIONAL) return GENDR_E_SHAPE;
+    if ((long)B * nf * T == 0) return GENDR_OK;
+    if (!vertices || !face_index || !textures || !out) return GENDR_E_NULL;
+    const long faces = (long)B * nf;
+    hipLaunchKernelGGL(light_faces_kernel, dim3((unsigned)((faces + kLightThreads - 1) / kLightThreads)), dim3(kLightThreads), 0,
+                       (hipStream_t)stream, vertices, face_index, textures, out, B, nv, nf, T, index_batched, *lp);
+    return check_launch();
+}
+
+int gendr_light_faces_backward(const float* vertices, const int* face_index, const float* textures, const float* grad_out,
+                               float* grad_textures, float* grad_vertices,
+                               int B, int nv, int nf, int T, int index_batched, const gendr_light_params* lp, void* stream)
+{
+    if (B < 0 || nv < 0 || nf < 0 || T < 0) return GENDR_E_SHAPE;
+    if (!lp) return GENDR_E_NULL;
+    if (lp->n_directional < 0 || lp->n_directional > GENDR_MAX_DIRECTIONAL) return GENDR_E_SHAPE;
+    if ((long)B * nf * T == 0) return GENDR_OK;
+    if (!vertices || !face_index || !textures || !grad_out) return GENDR_E_NULL;
+    const long faces = (long)B * nf;
+    hipLaunchKernelGGL(light_faces_backward_kernel, dim3((unsigned)((faces + kLightThreads - 1) / kLightThreads)), dim3(kLightThreads), 0,
+                       (hipStream_t)stream, vertices, face_index, textures, grad_out, grad_textures, grad_vertices,
+                       B, nv, nf, T, index_batched, *lp);
     return check_launch();
 }
 

@@ -126,12 +126,12 @@ __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ float clamped_norm(V3 v) { return fmaxf(__fsqrt_rn(dot(v, v)), 1e-5f); }
+__device__ __forceinline__ float clamped_norm(V3 v) { return fmaxf(sqrtf(dot(v, v)), 1e-5f); }
 __device__ __forceinline__ V3 normalize(V3 v) { const float n = clamped_norm(v); return {v.x / n, v.y / n, v.z / n}; }
 // gradient of normalize at v for upstream g
 __device__ __forceinline__ V3 normalize_grad(V3 v, V3 g)
 {
-    const float raw = __fsqrt_rn(dot(v, v));
+    const float raw = sqrtf(dot(v, v));
     if (raw < 1e-5f) return g * (1.0f / 1e-5f);                  // clamped: the denominator is a constant
     const V3 u = v * (1.0f / raw);
     return (g - u * dot(u, g)) * (1.0f / raw);

@@ -1,4 +1,6 @@
 """Lighting modules: textures are multiplied by ambient + directional light (reference ``gendr/lighting.py:11-71``)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -31,7 +33,26 @@ class Lighting(nn.Module):
         self.ambient = AmbientLighting(intensity_ambient, color_ambient)
         self.directionals = nn.ModuleList([DirectionalLighting(intensity_directionals, color_directionals, directions)])
 
+    def _fused_ok(self, mesh):
+        """One HIP kernel instead of the tensor chain: CUDA float32 surface textures, shared colours / directions."""
+        if os.environ.get('GENDR_FUSED_LIGHTING', '1') == '0' or mesh.texture_type != 'surface':
+            return False
+        if not (mesh.vertices.is_cuda and mesh.textures.is_cuda and mesh.textures.dtype == torch.float32):
+            return False
+        if len(self.directionals) > 4:
+            return False
+
+        def plain(v):
+            return isinstance(v, (tuple, list)) and len(v) == 3 and all(isinstance(x, (int, float)) for x in v)
+        mods = [self.ambient] + list(self.directionals)
+        return all(plain(m.light_color) and isinstance(m.light_intensity, (int, float)) for m in mods) and \
+            all(plain(d.light_direction) for d in self.directionals)
+
     def forward(self, mesh):
+        if self._fused_ok(mesh):
+            lit = Fn.light_faces(mesh.vertices, mesh.faces, mesh.textures, self.ambient.light_intensity, self.ambient.light_color,
+                                 [(d.light_intensity, d.light_color, d.light_direction) for d in self.directionals])
+            return Mesh(mesh.vertices, mesh.faces, lit, mesh.texture_res, mesh.texture_type)
         if mesh.texture_type == 'surface':
             shape, normals, expand = mesh.faces, 'surface_normals', True
         elif mesh.texture_type == 'vertex':

@@ -145,6 +145,26 @@ int gendr_create_texture_image(const float* face_uv, const float* textures, floa
 size_t gendr_voxelize_workspace_bytes(int B, int voxel_size);
 int gendr_voxelize(const float* faces, int* voxels, void* workspace, int B, int nf, int voxel_size, void* stream);
 
+/* Lighting of surface textures (gendr/lighting.py:48-71 with functional/lighting.py:11-48 and Mesh.surface_normals,
+ * gendr/mesh.py:109-117): out[b,f,t,:] = textures[b,f,t,:] * (ambient_intensity * ambient_color
+ *     + sum_i intensity[i] * (color[i] * relu(<n_f, direction[i]>))),  n_f = normalize(cross(v2 - v1, v0 - v1), eps 1e-6).
+ *   vertices [B,nv,3], face_index [B or 1,nf,3] i32, textures / out [B,nf,T,3].
+ * Backward: grad_textures [B,nf,T,3] is written, grad_vertices [B,nv,3] (zero-filled) accumulated; either may be NULL. */
+#define GENDR_MAX_DIRECTIONAL 4
+typedef struct {
+    float ambient_intensity;
+    float ambient_color[3];
+    int   n_directional;                                  /* 0..GENDR_MAX_DIRECTIONAL */
+    float intensity[GENDR_MAX_DIRECTIONAL];
+    float color[GENDR_MAX_DIRECTIONAL][3];
+    float direction[GENDR_MAX_DIRECTIONAL][3];
+} gendr_light_params;
+int gendr_light_faces(const float* vertices, const int* face_index, const float* textures, float* out,
+                      int B, int nv, int nf, int T, int index_batched, const gendr_light_params* lp, void* stream);
+int gendr_light_faces_backward(const float* vertices, const int* face_index, const float* textures, const float* grad_out,
+                               float* grad_textures, float* grad_vertices,
+                               int B, int nv, int nf, int T, int index_batched, const gendr_light_params* lp, void* stream);
+
 /* camera [B,12] from eye / target / up [B,3] each (look_at.py:52-59: z = normalize(at - eye), x = normalize(up x z),
  * y = normalize(z x x), F.normalize eps 1e-5; look.py: z = normalize(direction) when target_is_direction), and its
  * hand-derived backward (grad_eye / grad_target / grad_up may each be NULL). */
