@@ -139,7 +139,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('GENDR_BENCH_FORCE_DIST') == '1':     # the env var exercises the N>1 calls on one GPU
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
 

@@ -34,13 +34,28 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """Compile the library if it is missing or older than its sources; returns its path."""
+    """Compile the library if it is missing or older than its sources; returns its path.  Safe when several
+    processes (one per GPU) call it at once: one compiles under a file lock into a temporary name and renames, the
+    others find the library up to date when they get the lock."""
     if not (force or needs_build()):
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():
+                tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+                cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+                if verbose:
+                    print(" ".join(cmd[:-1] + [LIB_PATH]))
+                try:
+                    subprocess.check_call(cmd, cwd=CSRC)
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
