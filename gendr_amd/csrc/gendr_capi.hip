@@ -50,23 +50,21 @@ const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),   // opt_shape hard renderer (opt_shape.py:148-159)
 };
 
-const KernelEntry kGeneric[3] = {
-    { {-1, -1, -1, -1, kTexSurface1}, render_forward_kernel<-1, -1, -1, -1, kTexSurface1>, render_backward_kernel<-1, -1, -1, -1, kTexSurface1, 0>,
-      render_backward_kernel<-1, -1, -1, -1, kTexSurface1, 1> },
-    { {-1, -1, -1, -1, kTexVertex},   render_forward_kernel<-1, -1, -1, -1, kTexVertex>,   render_backward_kernel<-1, -1, -1, -1, kTexVertex, 0>,
-      render_backward_kernel<-1, -1, -1, -1, kTexVertex, 1> },
-    { {-1, -1, -1, -1, kTexSurfaceN}, render_forward_kernel<-1, -1, -1, -1, kTexSurfaceN>, render_backward_kernel<-1, -1, -1, -1, kTexSurfaceN, 0>,
-      render_backward_kernel<-1, -1, -1, -1, kTexSurfaceN, 1> },
-};
+// Runtime-dispatch kernels, four classes by what has to be compiled in: the 13 "light" distributions or all 18, the 5
+// "light" alpha aggregators (max ... hamacher) or all 10.  The heavy branches (gamma's series, the transcendental
+// t-conorms) cost registers, so an option set only pays for the heavy half it actually needs.  K = kernel suffix
+// (register budget): _wl light x light, _wa light distributions x all aggregators, _wf whenever the heavy
+// distributions are compiled in (their register need does not fit more than two waves per SIMD without heavy spills).
+#define GENDR_GENERIC_ROW(D, A, TEXM, K) \
+    { {D, A, -1, -1, TEXM}, render_forward_kernel_##K<D, A, -1, -1, TEXM>, render_backward_kernel_##K<D, A, -1, -1, TEXM, 0>, \
+      render_backward_kernel_##K<D, A, -1, -1, TEXM, 1> }
+#define GENDR_GENERIC_CLASS(D, A, K) \
+    { GENDR_GENERIC_ROW(D, A, kTexSurface1, K), GENDR_GENERIC_ROW(D, A, kTexVertex, K), GENDR_GENERIC_ROW(D, A, kTexSurfaceN, K) }
 
-// light runtime-dispatch kernels: 13 light distributions x 5 light alpha aggregators, any RGB / squared flag
-const KernelEntry kGenericLight[3] = {
-    { {-2, -2, -1, -1, kTexSurface1}, render_forward_kernel<-2, -2, -1, -1, kTexSurface1>, render_backward_kernel<-2, -2, -1, -1, kTexSurface1, 0>,
-      render_backward_kernel<-2, -2, -1, -1, kTexSurface1, 1> },
-    { {-2, -2, -1, -1, kTexVertex},   render_forward_kernel<-2, -2, -1, -1, kTexVertex>,   render_backward_kernel<-2, -2, -1, -1, kTexVertex, 0>,
-      render_backward_kernel<-2, -2, -1, -1, kTexVertex, 1> },
-    { {-2, -2, -1, -1, kTexSurfaceN}, render_forward_kernel<-2, -2, -1, -1, kTexSurfaceN>, render_backward_kernel<-2, -2, -1, -1, kTexSurfaceN, 0>,
-      render_backward_kernel<-2, -2, -1, -1, kTexSurfaceN, 1> },
+// [distribution class: 0 = all, 1 = light][alpha class: 0 = all, 1 = light][texture mode]
+const KernelEntry kGeneric[2][2][3] = {
+    { GENDR_GENERIC_CLASS(-1, -1, wf), GENDR_GENERIC_CLASS(-1, -2, wf) },
+    { GENDR_GENERIC_CLASS(-2, -1, wa), GENDR_GENERIC_CLASS(-2, -2, wl) },
 };
 
 const KernelEntry& pick_kernel(const gendr_params* p, int texm)
@@ -76,8 +74,7 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm)
             e.key.sq == (p->dist_squared ? 1 : 0) && e.key.texm == texm)
             return e;
     }
-    if (is_light_dist(p->dist_func) && is_light_alpha(p->aggr_alpha_func)) return kGenericLight[texm];
-    return kGeneric[texm];
+    return kGeneric[is_light_dist(p->dist_func) ? 1 : 0][is_light_alpha(p->aggr_alpha_func) ? 1 : 0][texm];
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }

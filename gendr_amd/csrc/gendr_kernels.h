@@ -37,6 +37,18 @@
 #ifndef GENDR_FWD_WAVES
 #define GENDR_FWD_WAVES 6
 #endif
+#ifndef GENDR_FULL_WAVES
+#define GENDR_FULL_WAVES 2
+#endif
+#ifndef GENDR_HALPHA_WAVES
+#define GENDR_HALPHA_WAVES 4
+#endif
+#ifndef GENDR_LIGHT_FWD_WAVES
+#define GENDR_LIGHT_FWD_WAVES 5
+#endif
+#ifndef GENDR_LIGHT_BWD_WAVES
+#define GENDR_LIGHT_BWD_WAVES 4
+#endif
 #ifndef GENDR_BWD_WAVES
 #define GENDR_BWD_WAVES 5
 #endif
@@ -1193,6 +1205,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_
     render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
 
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_LIGHT_FWD_WAVES))) void render_forward_kernel_wl(const RenderArgs a)
+{
+    render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_FULL_WAVES))) void render_forward_kernel_wf(const RenderArgs a)
+{
+    render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_HALPHA_WAVES))) void render_forward_kernel_wa(const RenderArgs a)
+{
+    render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
@@ -1460,6 +1488,23 @@ __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderA
 // register budget capped for 5 waves per SIMD (96 VGPRs), see render_forward_kernel_w6
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BWD_WAVES))) void render_backward_kernel_w5(const RenderArgs a)
+{
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+}
+
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_LIGHT_BWD_WAVES))) void render_backward_kernel_wl(const RenderArgs a)
+{
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+}
+
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_FULL_WAVES))) void render_backward_kernel_wf(const RenderArgs a)
+{
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+}
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_HALPHA_WAVES))) void render_backward_kernel_wa(const RenderArgs a)
 {
     render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
 }

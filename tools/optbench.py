@@ -18,6 +18,10 @@ CASES = [
     ('logistic/prob/softmax tau=3e-3 (spec)', dict(dist_func='logistic', dist_scale=3e-3)),
     ('logistic/einstein/softmax tau=3e-3 (generic)', dict(dist_func='logistic', dist_scale=3e-3, aggr_alpha_func='einstein')),
     ('gaussian/prob/hard tau=1e-2 (generic)', dict(dist_func='gaussian', aggr_rgb_func='hard')),
+    ('gudermannian/prob/softmax tau=3e-3 (full)', dict(dist_func='gudermannian', dist_scale=3e-3)),
+    ('uniform/frank(2)/softmax (full)', dict(aggr_alpha_func='frank', aggr_alpha_t_conorm_p=2.0)),
+    ('gudermannian/einstein/softmax tau=3e-3 (full)', dict(dist_func='gudermannian', dist_scale=3e-3, aggr_alpha_func='einstein')),
+    ('gamma(2)/yager(2)/softmax surface (full)', dict(dist_func='gamma', dist_shape=2.0, aggr_alpha_func='yager', aggr_alpha_t_conorm_p=2.0)),
 ]
 for name, o in CASES:
     oo, extra = parity.split_options(dict(o, double_side=False))
