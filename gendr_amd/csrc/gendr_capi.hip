@@ -41,11 +41,23 @@ struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd, bwd_wide; };   // 
     { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM, 0>, \
       render_backward_kernel_w5<D, A, RGB, SQ, TEXM, 1> }
 
+// same with explicit register-budget suffixes for the forward / backward kernels (_wl 5/4, _wa 4, _wf 2 waves per SIMD)
+#define GENDR_SPECIALISE_K2(D, A, RGB, SQ, TEXM, KF, KB) \
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_##KF<D, A, RGB, SQ, TEXM>, render_backward_kernel_##KB<D, A, RGB, SQ, TEXM, 0>, \
+      render_backward_kernel_##KB<D, A, RGB, SQ, TEXM, 1> }
+#define GENDR_SPECIALISE_K(D, A, RGB, SQ, TEXM, KF, KB) GENDR_SPECIALISE_K2(D, A, RGB, SQ, TEXM, KF, KB)
+
+#ifndef C5F
+#define C5F wa
+#endif
+#ifndef C5B
+#define C5B wa
+#endif
 const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 1, 0, kTexSurface1),   // C2 headline; library defaults
     GENDR_SPECIALISE_OCC(kGaussian,  kEinstein,      1, 1, kTexSurface1),   // C3
     GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 1, 0, kTexSurface1),   // C4
-    GENDR_SPECIALISE(kGamma,         kYager,         1, 0, kTexVertex),     // C5 (gamma's series needs its registers)
+    GENDR_SPECIALISE_K(kGamma,       kYager,         1, 0, kTexVertex, C5F, C5B),   // C5
     GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // opt_shape / train_reconstruction soft renderer (hard RGB)
     GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),   // opt_shape hard renderer (opt_shape.py:148-159)
 };
