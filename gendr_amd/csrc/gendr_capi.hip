@@ -47,6 +47,9 @@ struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd, bwd_wide; };   // 
       render_backward_kernel_##KB<D, A, RGB, SQ, TEXM, 1> }
 #define GENDR_SPECIALISE_K(D, A, RGB, SQ, TEXM, KF, KB) GENDR_SPECIALISE_K2(D, A, RGB, SQ, TEXM, KF, KB)
 
+#ifndef C2B
+#define C2B w5
+#endif
 #ifndef C5F
 #define C5F wa
 #endif
@@ -54,8 +57,8 @@ struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd, bwd_wide; };   // 
 #define C5B wa
 #endif
 const KernelEntry kSpecialised[] = {
-    GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 1, 0, kTexSurface1),   // C2 headline; library defaults
-    GENDR_SPECIALISE_OCC(kGaussian,  kEinstein,      1, 1, kTexSurface1),   // C3
+    GENDR_SPECIALISE_K(kUniform,     kProbabilistic, 1, 0, kTexSurface1, w6, C2B),  // C2 headline; library defaults
+    GENDR_SPECIALISE_K(kGaussian,    kEinstein,      1, 1, kTexSurface1, w6, wa),   // C3 (backward: 4 waves, less spill)
     GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 1, 0, kTexSurface1),   // C4
     GENDR_SPECIALISE_K(kGamma,       kYager,         1, 0, kTexVertex, C5F, C5B),   // C5
     GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // opt_shape / train_reconstruction soft renderer (hard RGB)
