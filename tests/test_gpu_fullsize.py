@@ -13,9 +13,14 @@ C2 = dict(dist_func='uniform', dist_scale=1e-2, aggr_alpha_func='probabilistic',
 C3 = dict(dist_func='gaussian', dist_scale=1e-4, dist_squared=True, aggr_alpha_func='einstein', double_side=False)
 
 
-def _scene(B):
+C4 = dict(dist_func='logistic', dist_scale=1e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax', double_side=False)
+C5 = dict(dist_func='gamma', dist_shape=2.0, dist_scale=1e-2, aggr_alpha_func='yager', aggr_alpha_t_conorm_p=2.0,
+          aggr_rgb_func='softmax', texture_type='vertex', double_side=False)
+
+
+def _scene(B, texture='surface'):
     from gendr_amd.synthetic import benchmark_scene
-    fv, tex = benchmark_scene(B)
+    fv, tex = benchmark_scene(B, texture=texture)
     return fv.numpy(), tex.numpy()
 
 
@@ -31,6 +36,18 @@ def test_one_full_frame_against_oracle(oracle_mod, native_lib, opts):
     else:
         grad = np.random.RandomState(1).randn(1, 4, 256, 256).astype(np.float32)
         assert not criteria.check(res, criteria.noise_floor(fv, tex, 256, opts, grad))
+
+
+@pytest.mark.parametrize("name,opts,isz", [('C4', C4, 512), ('C5', C5, 768)])
+def test_large_frames_against_oracle(oracle_mod, native_lib, name, opts, isz):
+    """C4 at its full size (long face lists: a 37-pixel cull radius); C5's option set (its own kernel, vertex colours)
+    at 768^2, large enough for backward to take the scalar phase-A walk (>= 400 image pixels per face)."""
+    fv, tex = _scene(2, texture='vertex' if name == 'C5' else 'surface')
+    fv, tex = fv[1:2], tex[1:2]
+    res, h, r = parity.compare(fv, tex, isz, opts)
+    grad = np.random.RandomState(1).randn(1, 4, isz, isz).astype(np.float32)
+    bad = criteria.check(res, criteria.noise_floor(fv, tex, isz, opts, grad))
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("opts", [C2, C3], ids=['C2', 'C3'])
