@@ -148,9 +148,12 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
 
 // Grid of a render kernel: a quarter of one-wave-per-tile (waves stride over their queue), a multiple of 8 so
 // that every XCD gets the same number of workgroups.
+#ifndef GENDR_GRID_DIV
+#define GENDR_GRID_DIV 4
+#endif
 int render_blocks(int total_blocks)
 {
-    const int quarter = (total_blocks + 3) / 4;
+    const int quarter = (total_blocks + GENDR_GRID_DIV - 1) / GENDR_GRID_DIV;
     return ((quarter + 7) / 8) * 8;
 }
 

@@ -1392,7 +1392,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                             // below 1e-6 the divisor is the double literal and the true divisions are kept.
                             const float len = q.dis;   // == sqrtf(dx*dx + dy*dy): the very value soft_fragment() computed (:771)
                             if ((double)len >= 1e-6) {
-                                const double rlen = 1. / (double)len;
+                                const double rlen = rcp_for_div_by((double)len);
 #pragma unroll
                                 for (int k = 0; k < 3; k++) {
                                     gv[3 * k + 0] = div_by(q.sign * C_xy * tw[k] * q.dx, rlen);

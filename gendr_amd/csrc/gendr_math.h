@@ -55,6 +55,21 @@ GENDR_HD DistParams make_dist_params(float scale, float shape, float shift)
 // a wavefront: three fp64-rate instructions instead of the IEEE f32 division expansion.
 GENDR_HD float div_by(float a, double rb) { return (float)((double)a * rb); }
 
+// Reciprocal of a positive, finite, normal double for use with div_by(): the argument above leaves 2^-49 - 2^-52 of
+// slack, so rb may be off by a few ulps.  On the device: v_rcp_f64 and two Newton steps (error < 2 ulp, 5
+// instructions) instead of the IEEE f64 division expansion (~15); on the host the true quotient.
+GENDR_HD double rcp_for_div_by(double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return r;
+#else
+    return 1. / b;
+#endif
+}
+
 GENDR_HD float quiet_nan() { return __builtin_nanf(""); }
 
 // normal CDF of a float argument (kernel.cu:293 calls CUDA's normcdf(float)).
