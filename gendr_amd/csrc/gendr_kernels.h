@@ -722,7 +722,8 @@ __device__ __forceinline__ float clip_and_depth(const Pair& q, const float* r, f
     wc[2] = fmaxf(fminf(q.w2, 1.f), 0.f);
     float s = wc[0] + wc[1] + wc[2];
     s = ((double)s > 1e-5) ? s : (float)1e-5;              // max(sum, 1e-5) with a double literal, stored as float
-    wc[0] /= s; wc[1] /= s; wc[2] /= s;
+    const double rs = rcp_for_div_by((double)s);           // three float quotients by one float divisor (s >= 1e-5)
+    wc[0] = div_by(wc[0], rs); wc[1] = div_by(wc[1], rs); wc[2] = div_by(wc[2], rs);
     return 1.f / (div_by(wc[0], rec_double(r, kRecRZ + 0)) + div_by(wc[1], rec_double(r, kRecRZ + 2)) + div_by(wc[2], rec_double(r, kRecRZ + 4)));   // "1. /": one rounding
 }
 
