@@ -167,7 +167,8 @@ def main():
         fv.grad = None
         tex.grad = None
         if record:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            # backward (the roofline kernel) on every sampled step, the forward phase only on the first one
+            e = [torch.cuda.Event(enable_timing=True) if (k >= 2 or not events) else None for k in range(4)]
             R.PROFILE_EVENTS = e
         img = R.render(fv, tex, image_size=isz, **opts)
         img.backward(grad)
@@ -185,9 +186,9 @@ def main():
         step(False)
     fence()
     # Kernel durations come from HIP events around the native calls, recorded live inside the timed region -- but
-    # only on a sample of the steps: a timed event drains the queue around it (about 10 us each on this stack, four
-    # per step cost 11 % of the throughput when every step carried them).
-    stride = max(1, args.steps // 4)
+    # only on a sample of the steps (three or four of them): a timed event drains the queue around it (about 10 us
+    # each on this stack, four per step cost 11 % of the throughput when every step carried them).
+    stride = max(1, args.steps // 3)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i % stride == 0)
@@ -199,7 +200,8 @@ def main():
         elapsed = float(t.item())
 
     # per-kernel durations from the HIP events recorded on the launch stream around the native calls
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
+    fwd_samples = [e for e in events if e[0] is not None]
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in fwd_samples) / len(fwd_samples)
     bwd_ms = sum(e[2].elapsed_time(e[3]) for e in events) / len(events)
 
     if rank == 0:

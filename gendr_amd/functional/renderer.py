@@ -147,11 +147,11 @@ def native_forward(faces, textures, params, rgba=None, aggrs_info=None):
                           dtype=torch.uint8, device=dev)
     ev = PROFILE_EVENTS
     with torch.cuda.device(dev):
-        if ev is not None:
+        if ev is not None and ev[0] is not None:
             ev[0].record()
         check(L.gendr_forward(_ptr(faces), _ptr(textures), _ptr(rgba), _ptr(aggrs_info), _ptr(records),
                               B, nf, T, ctypes.byref(params), _stream_ptr()), 'gendr_forward')
-        if ev is not None:
+        if ev is not None and ev[1] is not None:
             ev[1].record()
     return rgba, aggrs_info, records
 
