@@ -145,7 +145,7 @@ constexpr int kTexSurfaceN = 2;   // texture_type surface, T = R*R > 1: texels r
 __host__ __device__ constexpr int record_floats(int texm) { return texm == kTexSurface1 ? 56 : (texm == kTexVertex ? 60 : 48); }
 
 constexpr int kTile    = 8;     // one wavefront renders an 8x8 pixel tile
-constexpr int kThreads = 256;   // 4 independent wave-tiles per workgroup
+constexpr int kThreads = 64;    // one wave-tile per workgroup (measured: 64 > 128 > 256 > 512 threads, +6 % over 256)
 constexpr int kSplitMin = GENDR_SPLIT_MIN;   // a face's pairs are split over two batches if at least this many fit into the open one
 
 // Control block (ints) at the end of the workspace, zeroed by face_setup_kernel on every call:
