@@ -35,7 +35,7 @@
 
 // register budgets of the occupancy-capped kernel variants (waves per SIMD)
 #ifndef GENDR_FWD_WAVES
-#define GENDR_FWD_WAVES 6
+#define GENDR_FWD_WAVES 7
 #endif
 #ifndef GENDR_FULL_WAVES
 #define GENDR_FULL_WAVES 2
@@ -1198,8 +1198,9 @@ __global__ __launch_bounds__(kThreads) void render_forward_kernel(const RenderAr
     render_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
 
-// Same body, register budget capped for 6 waves per SIMD (80 VGPRs): used for the specialised option sets, whose
-// natural allocation sits a few registers above that step; the handful of spilled dwords costs less than the wave.
+// Same body, register budget capped for GENDR_FWD_WAVES (7) waves per SIMD (72 VGPRs): used for the specialised option
+// sets, whose natural allocation sits a few registers above an occupancy step; the handful of spilled dwords costs
+// less than the waves (the _w6 / _w5 suffixes date from the first budgets tried).
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_FWD_WAVES))) void render_forward_kernel_w6(const RenderArgs a)
 {
