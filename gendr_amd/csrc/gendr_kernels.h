@@ -22,7 +22,7 @@
 //     component) instead of 12..84 per (pixel, face);
 //   * inside the loop every pair still passes the reference's own three skip tests, so culling only removes pairs
 //     that contribute exactly nothing;
-//   * everything is wave-local: no workgroup barriers in the render kernels, 4 independent wave-tiles per workgroup.
+//   * everything is wave-local: no workgroup barriers in the render kernels, one wave-tile per workgroup.
 //
 // No MFMA: there is no dense contraction in this path.  Compiled with -ffp-contract=off.
 #pragma once
