@@ -1,23 +1,35 @@
 #!/usr/bin/env python
 """Headline benchmark: generalized soft rasterizer forward + backward, frames/s.
 
-Workload (BASELINE.json configs[1], "C2"): synthetic 1280-face mesh, 256x256, batch 64 per GPU,
+Workload (BASELINE.json configs[1], "C2"): synthetic 1280-face mesh, 256x256, GLOBAL batch 64,
 dist_func=uniform, aggr_alpha_func=probabilistic, aggr_rgb_func=softmax, tau=1e-2, library defaults
 otherwise.  A step = one forward and one backward of the autograd Function (`gendr_amd.functional.render`)
-on inputs already resident in HBM.  Multi-GPU: one process per GPU (torch.distributed, RCCL), the batch
-axis is sharded, no collective on the data path, weak scaling (64 frames per GPU).
+on inputs already resident in HBM.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), the batch axis is
+sharded evenly -- STRONG scaling: 64 frames in total, 64/N per GPU -- and the data path has no collective.
+`python bench.py --gpus N` starts the N ranks itself when it is not already running under torchrun
+(WORLD_SIZE unset); under the driver's `python -m torch.distributed.run ... bench.py --gpus N` it reads
+RANK / LOCAL_RANK / WORLD_SIZE from the environment.  The weak-scaling figure (64 frames per GPU) is measured
+in the same run and reported under "extra".
+
+`--config c4` is BASELINE config 4: 256 views of 512^2 sharded over the ranks, and the step is
+render -> all-gather of the views (`gendr_amd.dist.gather_views`) -> a loss that couples every view ->
+backward (reduce-scatter of the view gradients, then the rasterizer's backward); the collective's share of the
+step is reported.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline":     algorithmic HBM bytes of the dominant kernel / its measured average duration vs 8 TB/s
-  "cpu_baseline": the CPU oracle (C port of the reference arithmetic, OpenMP) timed on this box's cores.
+  "cpu_baseline": the pure-PyTorch evaluation of the same per-pixel math on all host cores (bounded sample);
+                  "cpu_baseline_oracle" is the C/OpenMP oracle on the same cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,14 +37,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6290 GB/s measured achievable
 
 CONFIGS = {
-    # name: (batch per GPU, subdivisions, image_size, render options, texture)
+    # name: (GLOBAL batch, subdivisions, image_size, render options, texture)
     'c2': dict(batch=64, subdiv=3, image_size=256, texture='surface',
                opts=dict(dist_func='uniform', dist_scale=1e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax')),
     'c3': dict(batch=64, subdiv=3, image_size=256, texture='surface',
                opts=dict(dist_func='gaussian', dist_scale=1e-4, dist_squared=True, aggr_alpha_func='einstein', aggr_rgb_func='softmax')),
-    'c4': dict(batch=32, subdiv=3, image_size=512, texture='surface',
+    'c4': dict(batch=256, subdiv=3, image_size=512, texture='surface', gather=True,
                opts=dict(dist_func='logistic', dist_scale=1e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax')),
-    'c5': dict(batch=8, subdiv=3, image_size=2048, texture='vertex',
+    'c5': dict(batch=32, subdiv=3, image_size=2048, texture='vertex',
                opts=dict(dist_func='gamma', dist_shape=2.0, dist_scale=1e-2, aggr_alpha_func='yager', aggr_alpha_t_conorm_p=2.0,
                          aggr_rgb_func='softmax', texture_type='vertex')),
 }
@@ -48,8 +60,11 @@ def algorithmic_bytes(P, nf, T):
     return fwd, bwd
 
 
-def cpu_baseline(cfg, fv, tex, target_seconds=15.0):
-    """Times the CPU oracle (oracle/, test infrastructure used here only as the reported baseline)
+# ------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; bounded samples)
+# ------------------------------------------------------------------------------------------------------------
+def cpu_baseline_oracle(cfg, fv, tex, target_seconds=12.0):
+    """Times the CPU oracle (oracle/, test infrastructure used here only as a reported baseline)
     on a bounded sample of the same workload with all host cores."""
     import numpy as np
     import oracle
@@ -79,6 +94,7 @@ def cpu_baseline(cfg, fv, tex, target_seconds=15.0):
 
 
 def _torch_baseline_worker(q, cfg, fv, tex, stride, threads):
+    import torch
     from oracle import torch_ref
     torch.set_num_threads(threads)
     opts = dict(cfg['opts'])
@@ -90,11 +106,11 @@ def _torch_baseline_worker(q, cfg, fv, tex, stride, threads):
     q.put(time.perf_counter() - t0)
 
 
-def cpu_baseline_torch(cfg, fv, tex, stride=8, threads=16, timeout=150):
-    """The pure-PyTorch evaluation of the same per-pixel math (oracle/torch_ref.py), which BASELINE.json's
-    north_star asks for next to the GPU number.  It evaluates every (pixel, face) pair, so its cost is linear in
-    the face count: a BOUNDED sample (1 frame, every `stride`-th face) is timed in a child process with a hard
-    timeout and scaled by `stride`.  Only for option sets the restatement covers."""
+def cpu_baseline_torch(cfg, fv, tex, stride=4, timeout=150):
+    """The pure-PyTorch evaluation of the same per-pixel math (oracle/torch_ref.py) that BASELINE.json's
+    north_star asks for next to the GPU number, on ALL host cores.  It evaluates every (pixel, face) pair, so its
+    cost is linear in the face count: a BOUNDED sample (1 frame, every `stride`-th face) is timed in a child
+    process with a hard timeout and scaled by `stride`.  Only for option sets the restatement covers."""
     import multiprocessing as mp
     from oracle import torch_ref
     opts = cfg['opts']
@@ -102,7 +118,10 @@ def cpu_baseline_torch(cfg, fv, tex, stride=8, threads=16, timeout=150):
         return None
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    threads = max(1, min(threads, os.cpu_count() or 1))
+    threads = max(1, os.cpu_count() or 1)
+    isz = cfg['image_size']
+    while stride < 64 and isz * isz * (fv.shape[1] // stride) > 40e6:      # bound the sample for the large configs
+        stride *= 2
     p = ctx.Process(target=_torch_baseline_worker, args=(q, cfg, fv[:1].cpu(), tex[:1].cpu(), stride, threads))
     p.start()
     p.join(timeout)
@@ -116,142 +135,326 @@ def cpu_baseline_torch(cfg, fv, tex, stride=8, threads=16, timeout=150):
     nf = fv.shape[1]
     return dict(value=1.0 / dt, unit='frames/s', cores=threads, kind='port',
                 sample='1 frame, every %dth of the %d faces (all-pairs evaluation, linear in faces), forward+backward, '
-                       'vectorised pure PyTorch (oracle/torch_ref.py) on %d threads; %.1f s scaled x%d'
+                       'vectorised pure PyTorch (oracle/torch_ref.py), torch.set_num_threads(%d) = all host cores; %.1f s scaled x%d'
                        % (stride, nf, threads, dt / stride, stride))
 
 
-def main():
+# ------------------------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` outside torchrun starts its own N ranks
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """Re-executes this script as n ranks of one node through torch.distributed.run (rendezvous on 127.0.0.1).
+    Rank 0's JSON line is the only thing the children print on stdout."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
-    ap.add_argument('--batch', type=int, default=None, help='frames per GPU (default: the config\'s)')
+    ap.add_argument('--batch', type=int, default=None, help='GLOBAL batch (default: the config\'s)')
+    ap.add_argument('--scaling', default='strong', choices=('strong', 'weak'),
+                    help='strong: the global batch is fixed and sharded (headline); weak: the config\'s batch per GPU')
+    ap.add_argument('--launch', default='eager', choices=('eager', 'graph'),
+                    help='graph: the step is captured once in a HIP graph and replayed (configs without a collective)')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo with --stub)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the second (weak-scaling) measurement at N > 1')
     ap.add_argument('--no-cull', action='store_true', help='visit every (pixel, face) pair (diagnostic)')
-    args = ap.parse_args()
+    ap.add_argument('--stub', action='store_true',
+                    help='no GPU: the step is a small CPU tensor op (exercises launcher, sharding, timing and JSON on gloo)')
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------------------
+# one measurement: W warm-up steps, K timed steps between fences, max over ranks
+# ------------------------------------------------------------------------------------------------------------
+class Workload:
+    """The per-rank shard of a config and its step function."""
+
+    def __init__(self, args, cfg, rank, world, dev, scaling):
+        import torch
+        from gendr_amd.dist import shard_range
+        from gendr_amd.synthetic import benchmark_scene
+        self.torch = torch
+        self.cfg, self.rank, self.world, self.dev = cfg, rank, world, dev
+        self.isz = cfg['image_size']
+        self.opts = dict(cfg['opts'])
+        self.opts.setdefault('double_side', False)          # gendr.GenDR() default (gendr/renderer.py:34)
+        base = args.batch or cfg['batch']
+        self.global_batch = base if scaling == 'strong' else base * world
+        a, b = shard_range(self.global_batch, rank, world)
+        if cfg.get('gather') and self.global_batch % world:
+            raise SystemExit('config %s needs a global batch divisible by the number of ranks' % args.config)
+        self.B = b - a
+        # every rank renders its own shard of views: the cameras differ per view
+        fv_all, tex_all = benchmark_scene(self.global_batch, subdivisions=cfg['subdiv'], texture=cfg['texture'], seed=0)
+        self.fv_cpu, self.tex_cpu = fv_all, tex_all
+        if args.stub:
+            self.fv = fv_all[a:b].clone().requires_grad_(True)
+            self.tex = tex_all[a:b].clone().requires_grad_(True)
+            self.nf, self.T = self.fv.shape[1], self.tex.shape[2]
+            return
+        self.fv = fv_all[a:b].to(dev).requires_grad_(True)
+        self.tex = tex_all[a:b].to(dev).requires_grad_(True)
+        self.nf, self.T = self.fv.shape[1], self.tex.shape[2]
+        g = torch.Generator(device='cpu').manual_seed(1 + a)
+        self.grad = torch.randn(max(self.B, 1), 4, self.isz, self.isz, generator=g)[:self.B].to(dev)
+        if cfg.get('gather'):
+            # weights of the coupling loss: every rank holds the weights of ALL views (different per rank)
+            self.w_all = torch.rand(self.global_batch, 1, 1, generator=g).to(dev)
+
+    def step_stub(self):
+        (self.fv * 2.0).sum().backward()
+
+    def step(self, events=None):
+        """One forward + backward.  `events`: four torch.cuda.Event (fwd start/end, bwd start/end) recorded on the
+        launch stream around the native calls, or None."""
+        from gendr_amd.functional import renderer as R
+        self.fv.grad = None
+        self.tex.grad = None
+        R.PROFILE_EVENTS = events
+        try:
+            img = R.render(self.fv, self.tex, image_size=self.isz, **self.opts)
+            if self.cfg.get('gather'):
+                from gendr_amd.dist import gather_views
+                views = gather_views(img, assume_equal_blocks=True)                                # [global batch, 4, is, is] on every rank
+                sil = views[:, 3]
+                # couples every view: weighted silhouettes against the mean silhouette over ALL views
+                loss = ((sil - sil.mean(0, keepdim=True)) ** 2 * self.w_all).mean() + (views[:, :3] * self.w_all[:, None]).mean()
+                loss.backward()
+            else:
+                img.backward(self.grad)
+        finally:
+            R.PROFILE_EVENTS = None
+
+
+def measure(args, wl, dist, dev):
+    """Returns dict(elapsed, fwd_ms, bwd_ms, n_events, coll_ms, launch)."""
+    torch = wl.torch
+    stub = args.stub
+
+    def fence():
+        if not stub:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        if not stub:
+            torch.cuda.synchronize()
+
+    if stub:
+        for _ in range(args.warmup):
+            wl.step_stub()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step_stub()
+        fence()
+        elapsed = time.perf_counter() - t0
+        launch = 'stub'
+        events, coll = [], []
+    else:
+        import gendr_amd.dist as gdist
+        launch = args.launch
+        if launch == 'graph' and wl.cfg.get('gather'):
+            launch = 'eager'                          # a collective inside the step: not captured
+        graph = None
+        for _ in range(args.warmup):
+            wl.step()
+        if launch == 'graph' and wl.B > 0:
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(3):
+                        wl.step()
+                torch.cuda.current_stream().wait_stream(s)
+                wl.fv.grad = None
+                wl.tex.grad = None
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    wl.step()
+                for _ in range(2):
+                    graph.replay()
+            except Exception as e:                    # capture refused on this stack: measure eagerly and say so
+                sys.stderr.write('bench: graph capture failed (%s); eager launches\n' % (e,))
+                graph = None
+                launch = 'eager'
+        fence()
+        # Kernel durations come from HIP events around the native calls, recorded live inside the timed region -- but
+        # only on a sample of the steps (three or four of them): a timed event drains the queue around it (about
+        # 10 us each on this stack; four per step cost 11 % of the throughput when every step carried them).
+        # Sampled steps are always launched eagerly (an event cannot be recorded inside a replayed graph).
+        events, coll = [], []
+        stride = max(1, args.steps // 3)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if i % stride == 0 and wl.B > 0:
+                e = [torch.cuda.Event(enable_timing=True) if (k >= 2 or not events) else None for k in range(4)]
+                if wl.cfg.get('gather'):
+                    gdist.PROFILE_EVENTS = c = []
+                wl.step(e)
+                gdist.PROFILE_EVENTS = None
+                events.append(e)
+                if wl.cfg.get('gather'):
+                    coll.append(c)
+            elif graph is not None:
+                graph.replay()
+            else:
+                wl.step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if stub else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = dict(elapsed=elapsed, launch=launch, fwd_ms=None, bwd_ms=None, n_events=len(events), coll_ms=None)
+    if events:
+        fwd_samples = [e for e in events if e[0] is not None]
+        out['fwd_ms'] = sum(e[0].elapsed_time(e[1]) for e in fwd_samples) / len(fwd_samples)
+        out['bwd_ms'] = sum(e[2].elapsed_time(e[3]) for e in events) / len(events)
+    if coll and all(coll):
+        out['coll_ms'] = sum(sum(a.elapsed_time(b) for a, b in c) for c in coll) / len(coll)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != max(1, args.gpus) and 'WORLD_SIZE' in os.environ:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if args.no_cull:
         os.environ['GENDR_CULL'] = '0'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1 or os.environ.get('GENDR_BENCH_FORCE_DIST') == '1':     # the env var exercises the N>1 calls on one GPU
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
 
-    from gendr_amd import build
-    build.build()
-    from gendr_amd.functional import renderer as R
-    from gendr_amd.synthetic import benchmark_scene
+    dev = None
+    oversub = os.environ.get('GENDR_BENCH_OVERSUBSCRIBE') == '1'      # several ranks on one GPU (1-GPU boxes, tests)
+    if not args.stub:
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev and not oversub:
+            raise SystemExit('bench.py: rank %d has no GPU (%d visible); GENDR_BENCH_OVERSUBSCRIBE=1 shares GPUs' % (local_rank, ndev))
+        torch.cuda.set_device(local_rank % max(ndev, 1))
+        dev = torch.device('cuda', local_rank % max(ndev, 1))
+    dist = None
+    backend = args.backend or ('gloo' if (args.stub or oversub) else 'nccl')   # RCCL refuses two ranks on one device
+    if world > 1 or os.environ.get('GENDR_BENCH_FORCE_DIST') == '1':          # the env var exercises the N>1 calls on one GPU
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
+
+    if not args.stub:
+        from gendr_amd import build
+        build.build()
 
     cfg = dict(CONFIGS[args.config])
-    B = args.batch or cfg['batch']
-    isz = cfg['image_size']
-    opts = dict(cfg['opts'])
-    opts.setdefault('double_side', False)          # gendr.GenDR() default (gendr/renderer.py:34)
-    # each rank renders its own shard of views: distinct cameras per rank
-    fv_all, tex_all = benchmark_scene(B * world, subdivisions=cfg['subdiv'], texture=cfg['texture'], seed=0)
-    fv = fv_all[rank * B:(rank + 1) * B].to(dev).requires_grad_(True)
-    tex = tex_all[rank * B:(rank + 1) * B].to(dev).requires_grad_(True)
-    nf, T = fv.shape[1], tex.shape[2]
-    g = torch.Generator(device='cpu').manual_seed(1 + rank)
-    grad = torch.randn(B, 4, isz, isz, generator=g).to(dev)
-
-    events = []
-
-    def step(record):
-        fv.grad = None
-        tex.grad = None
-        if record:
-            # backward (the roofline kernel) on every sampled step, the forward phase only on the first one
-            e = [torch.cuda.Event(enable_timing=True) if (k >= 2 or not events) else None for k in range(4)]
-            R.PROFILE_EVENTS = e
-        img = R.render(fv, tex, image_size=isz, **opts)
-        img.backward(grad)
-        if record:
-            events.append(e)
-            R.PROFILE_EVENTS = None
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    # Kernel durations come from HIP events around the native calls, recorded live inside the timed region -- but
-    # only on a sample of the steps (three or four of them): a timed event drains the queue around it (about 10 us
-    # each on this stack, four per step cost 11 % of the throughput when every step carried them).
-    stride = max(1, args.steps // 3)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i % stride == 0)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel durations from the HIP events recorded on the launch stream around the native calls
-    fwd_samples = [e for e in events if e[0] is not None]
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in fwd_samples) / len(fwd_samples)
-    bwd_ms = sum(e[2].elapsed_time(e[3]) for e in events) / len(events)
+    wl = Workload(args, cfg, rank, world, dev, args.scaling)
+    m = measure(args, wl, dist, dev)
+    extra = {}
+    if world > 1 and not args.no_extra and not cfg.get('gather') and args.scaling == 'strong':
+        wl_weak = Workload(args, cfg, rank, world, dev, 'weak')
+        mw = measure(args, wl_weak, dist, dev)
+        extra['weak'] = {'value': wl_weak.global_batch * args.steps / mw['elapsed'], 'unit': 'frames/s',
+                         'global_batch': wl_weak.global_batch, 'ms_per_step': mw['elapsed'] / args.steps * 1e3,
+                         'scaling': 'weak', 'launch': mw['launch']}
+        del wl_weak
 
     if rank == 0:
+        isz, nf, T, B = wl.isz, wl.nf, wl.T, wl.B
         P = isz * isz
         fwd_b, bwd_b = algorithmic_bytes(P, nf, T)
-        # The longest single kernel is the backward render kernel (the forward phase is three launches: face setup,
-        # binning, forward render); the events around the backward native call bracket exactly that one kernel.
-        dom = 'render_backward_kernel'
-        dom_bytes = bwd_b * B
-        dom_ms = bwd_ms
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.config)
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch', {}).get(dom)
-            except Exception:
-                traffic = None
+        opts = wl.opts
+        elapsed = m['elapsed']
         out = {
-            'metric': 'soft_rasterize fwd+bwd frames/s @%d^2, %d faces, batch %d per GPU' % (isz, nf, B),
-            'value': world * B * args.steps / elapsed,
+            'metric': 'soft_rasterize fwd+bwd frames/s @%d^2, %d faces, batch %d' % (isz, nf, wl.global_batch),
+            'value': wl.global_batch * args.steps / elapsed,
             'unit': 'frames/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s: %d-face icosphere variant, %dx%d, %s, batch %d per GPU, T=%d, double_side=%s, dist_eps=1e4'
+            'config': {'workload': '%s: %d-face icosphere variant, %dx%d, %s, global batch %d (%d on rank 0), T=%d, double_side=%s, dist_eps=1e4%s'
                                    % (args.config.upper(), nf, isz, isz,
                                       '/'.join(str(opts[k]) for k in ('dist_func', 'aggr_alpha_func', 'aggr_rgb_func')),
-                                      B, T, opts['double_side']),
-                       'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
+                                      wl.global_batch, B, T, opts['double_side'],
+                                      '; step = render -> all-gather of views -> coupled loss -> backward (reduce-scatter)' if cfg.get('gather') else ''),
+                       'global_batch': wl.global_batch,
+                       'parallelism': ('batch-sharded x%d, ' % world) + ('RCCL all-gather / reduce-scatter of views' if cfg.get('gather') and world > 1
+                                                                          else 'no data-path collective'),
+                       'backend': (backend if dist is not None else None),
+                       'launch': m['launch'],
                        'cull': os.environ.get('GENDR_CULL', '1') != '0'},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
-                         'note': 'VALU-bound path (SURVEY.md H2); whole-op fraction = %.4f'
-                                 % ((fwd_b + bwd_b) * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS)},
-            'kernel_ms': {'forward_phase': fwd_ms, 'backward_phase': bwd_ms, 'event_samples': len(events)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, fv_all[:B], tex_all[:B])
-            tb = cpu_baseline_torch(cfg, fv_all[:B], tex_all[:B])
+        if m['bwd_ms'] is not None:
+            # The longest single kernel is the backward render kernel; the events around the backward native call
+            # bracket exactly that launch (plus, since round 2, nothing else: the gradient zero fill happens before).
+            dom = 'render_backward_kernel'
+            dom_bytes = bwd_b * B
+            dom_ms = m['bwd_ms']
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+            traffic, source = None, None
+            pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.config)
+            if os.path.exists(pmc_path):
+                try:
+                    traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch', {}).get(dom)
+                    source = ('profiles/pmc_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the '
+                              'config\'s single-GPU batch (profiles/run_traffic.sh), 2*FETCH+WRITE; not re-measured in this run' % args.config)
+                except Exception:
+                    traffic = None
+            out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': source,
+                               'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
+                               'note': 'VALU-bound path (SURVEY.md H2); whole-op fraction on rank 0 = %.4f'
+                                       % ((fwd_b + bwd_b) * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS)}
+            out['kernel_ms'] = {'forward_phase': m['fwd_ms'], 'backward_phase': m['bwd_ms'], 'event_samples': m['n_events']}
+        if m['coll_ms'] is not None:
+            out['collective'] = {'ms_per_step': m['coll_ms'], 'share_of_step': m['coll_ms'] / (elapsed / args.steps * 1e3),
+                                 'what': 'all_gather_into_tensor of [%d,4,%d,%d] f32 views + reduce_scatter_tensor of their gradients'
+                                         % (wl.global_batch, isz, isz)}
+        if extra:
+            out['extra'] = extra
+        if world == 1 and not args.no_cpu_baseline and not args.stub:
+            nb = min(B, 64)
+            oc = cpu_baseline_oracle(cfg, wl.fv_cpu[:nb], wl.tex_cpu[:nb])
+            tb = cpu_baseline_torch(cfg, wl.fv_cpu[:nb], wl.tex_cpu[:nb])
             if tb is not None:
-                out['cpu_baseline_torch'] = tb
-        print(json.dumps(out))
+                out['cpu_baseline'] = tb
+                out['cpu_baseline_oracle'] = oc
+            else:
+                oc['note'] = 'oracle/torch_ref.py does not cover this option set; C/OpenMP oracle instead'
+                out['cpu_baseline'] = oc
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -243,9 +243,13 @@ float gendr_t_conorm_backward(int t_conorm_id, float a_all, float b_current, int
 // Distance d (NDC) such that every outside pixel farther than d from the triangle is skipped by the
 // reference itself: either D(-x) <= 1e-6 (kernel.cu:784; searched against half that threshold so that the
 // few-ulp difference between host and device libm cannot matter) or d^2 >= dist_eps * tau (kernel.cu:769).
-float gendr_cull_radius(const gendr_params* p)
+// D(-x) is not exactly monotone in float arithmetic (wigner_semicircle loses ~1e-6 to cancellation right where it
+// crosses the threshold), so the bisection's crossing is only a candidate: a sweep over [candidate, search end]
+// then moves the radius beyond the LAST argument at which D(-x) still exceeds the limit
+// (tests/test_host_logic.py::test_cull_radius_is_an_upper_bound_for_every_distribution scans the result).
+// The sweep costs a few thousand CDF evaluations, so the result is cached per thread for the last option set.
+static float cull_radius_uncached(const gendr_params* p)
 {
-    if (!p || !p->cull) return INFINITY;
     const float thr = p->dist_eps * p->dist_scale;
     float r_eps = sqrtf(thr) * (1.f + 1e-6f) + 1e-30f;
     if (!(r_eps == r_eps)) r_eps = INFINITY;
@@ -266,10 +270,52 @@ float gendr_cull_radius(const gendr_params* p)
             const float fm = cdf_rt(p->dist_func, -1.f, mid, d);
             if (fm == fm && (double)fm <= limit) hi = mid; else lo = mid;
         }
+        // verification sweep: a fine linear grid over [hi, 2 hi] (where rounding noise competes with the limit) and
+        // a geometric grid up to the search end; the radius moves past the last offender
+        const int kLin = 2048, kGeo = 2048;
+        const float start = hi > 0.f ? hi : 1e-12f;
+        float last_bad = -1.f, after_bad = x_hi;      // last offending sample and the first clean sample behind it
+        const double ratio = (double)x_hi / (double)start;
+        for (int i = 0; i <= kLin + kGeo; i++) {
+            const float x = i <= kLin ? start * (1.f + (float)i / kLin)
+                                      : (float)((double)start * pow(ratio, (double)(i - kLin) / kGeo));
+            if (!(x <= x_hi)) continue;
+            const float fx = cdf_rt(p->dist_func, -1.f, x, d);
+            if (!(fx == fx && (double)fx <= limit)) { if (x > last_bad) { last_bad = x; after_bad = x_hi; } }
+            else if (x > last_bad && x < after_bad) after_bad = x;
+        }
+        if (last_bad >= 0.f) {
+            // the offending region ends between the two samples (a cut like gamma's xs / tau > 15 is a jump): bisect
+            float blo = last_bad, bhi = after_bad;
+            for (int it = 0; it < 48; it++) {
+                const float mid = 0.5f * (blo + bhi);
+                if (mid <= blo || mid >= bhi) break;
+                const float fm = cdf_rt(p->dist_func, -1.f, mid, d);
+                if (fm == fm && (double)fm <= limit) bhi = mid; else blo = mid;
+            }
+            hi = fmaxf(hi, bhi);
+        }
+        // wigner_semicircle evaluates tau^2 - x^2 in float: up to ~1e-6 of cancellation noise on D right where it
+        // crosses the limit, isolated spikes a sweep cannot see.  Beyond its support end (u < -1) it is exactly 0.
+        if (p->dist_func == kWigner) hi = fmaxf(hi, p->dist_scale);
         r_cdf = p->dist_squared ? sqrtf(hi) : hi;
         r_cdf = r_cdf * (1.f + 1e-6f);
     }
     return fminf(r_cdf, r_eps);
+}
+
+float gendr_cull_radius(const gendr_params* p)
+{
+    if (!p || !p->cull) return INFINITY;
+    struct Key { int dist, squared; float scale, shape, shift, eps; };
+    static thread_local Key last = {-1, 0, 0.f, 0.f, 0.f, 0.f};
+    static thread_local float last_r = 0.f;
+    const Key k = {p->dist_func, p->dist_squared ? 1 : 0, p->dist_scale, p->dist_shape, p->dist_shift, p->dist_eps};
+    if (memcmp(&k, &last, sizeof(Key)) == 0) return last_r;
+    const float r = cull_radius_uncached(p);
+    last = k;
+    last_r = r;
+    return r;
 }
 
 int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* stream)

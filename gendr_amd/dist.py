@@ -11,21 +11,58 @@ import torch
 import torch.distributed as dist
 
 
-def shard_range(n, rank=None, world=None):
+# bench.py sets this to a list; every collective of gather_views then appends a (start, end) pair of
+# torch.cuda.Event recorded on the current stream around it (CUDA tensors only).  None = no timing.
+PROFILE_EVENTS = None
+
+
+def shard_range(n, rank=None, world=None, group=None):
     """Contiguous [start, stop) slice of ``n`` batch items owned by ``rank`` (remainder to the low ranks)."""
     if world is None:
-        world = dist.get_world_size() if dist.is_initialized() else 1
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
     if rank is None:
-        rank = dist.get_rank() if dist.is_initialized() else 0
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
     base, rem = divmod(n, world)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
 
 
-def shard_batch(t, rank=None, world=None):
+def shard_batch(t, rank=None, world=None, group=None):
     """The slice of the leading (batch / view) axis this rank renders."""
-    a, b = shard_range(t.shape[0], rank, world)
+    a, b = shard_range(t.shape[0], rank, world, group)
     return t[a:b]
+
+
+class _Timed:
+    """Brackets a collective with two events on the current stream when bench.py asked for it."""
+
+    def __init__(self, t):
+        self.on = PROFILE_EVENTS is not None and t.is_cuda
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            PROFILE_EVENTS.append((self.a, b))
+        return False
+
+
+def _check_equal_blocks(n_local, group):
+    """all_gather_into_tensor / reduce_scatter_tensor need the same block size on every rank: unequal blocks hang
+    or corrupt on NCCL / RCCL instead of failing.  One tiny all-reduce (min and max of the local size)."""
+    t = torch.tensor([n_local, -n_local], dtype=torch.int64)
+    if dist.get_backend(group) != 'gloo':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    lo, hi = -int(t[1]), int(t[0])
+    if lo != hi:
+        raise ValueError('gather_views needs equally sized per-rank view blocks (got %d..%d views per rank); '
+                         'pad the batch or shard it evenly' % (lo, hi))
 
 
 class _GatherViews(torch.autograd.Function):
@@ -33,34 +70,42 @@ class _GatherViews(torch.autograd.Function):
     (each rank receives the sum over ranks of the gradient w.r.t. its own block)."""
 
     @staticmethod
-    def forward(ctx, x, group):
+    def forward(ctx, x, group, checked):
         ctx.group = group
         world = dist.get_world_size(group)
+        if not checked:
+            _check_equal_blocks(x.shape[0], group)
         x = x.contiguous()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=group)
+        with _Timed(x):
+            dist.all_gather_into_tensor(out, x, group=group)
         return out
 
     @staticmethod
     def backward(ctx, grad):
         group = ctx.group
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        grad = grad.contiguous()
         n = grad.shape[0] // world
-        if dist.get_backend(group) == 'gloo':          # gloo has no reduce_scatter: all-reduce and slice
-            dist.all_reduce(grad, group=group)
-            return grad[rank * n:(rank + 1) * n].clone(), None
+        if dist.get_backend(group) == 'gloo':          # gloo has no reduce_scatter: all-reduce a private copy and slice
+            total = grad.clone(memory_format=torch.contiguous_format)   # never reduce in place into autograd's own buffer
+            with _Timed(total):
+                dist.all_reduce(total, group=group)
+            return total[rank * n:(rank + 1) * n].clone(), None, None
+        grad = grad.contiguous()
         out = torch.empty((n,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
-        dist.reduce_scatter_tensor(out, grad, group=group)
-        return out, None
+        with _Timed(grad):
+            dist.reduce_scatter_tensor(out, grad, group=group)
+        return out, None, None
 
 
-def gather_views(images, group=None):
+def gather_views(images, group=None, assume_equal_blocks=False):
     """[B_local, ...] on every rank -> [world * B_local, ...] on every rank, differentiable.
-    A no-op without an initialised process group (single GPU)."""
+    A no-op without an initialised process group (single GPU).  Every rank must hand over the same number of
+    views; that is verified with one small all-reduce per call unless ``assume_equal_blocks`` (callers that
+    sharded with an even ``shard_range`` already know)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return images
-    return _GatherViews.apply(images, group)
+    return _GatherViews.apply(images, group, assume_equal_blocks)
 
 
 def sum_over_ranks(t, group=None):

@@ -22,7 +22,9 @@ def _as_vec3(v, device, batch):
     elif torch.is_tensor(v):
         v = v.to(device)
     if v.dim() == 1:
-        v = v[None, :].expand(batch, 3)
+        v = v[None, :]
+    if v.dim() == 2 and v.shape[0] == 1 and batch != 1:      # [1,3] broadcasts over the batch, as in the reference
+        v = v.expand(batch, v.shape[1])
     return v
 
 

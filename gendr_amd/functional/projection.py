@@ -24,18 +24,16 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-_validated = {}
-
-
 def _check_indices(faces, nv):
-    """Range check of the face indices (a host sync), once per index tensor version.  Error reporting only: the
-    kernels never read outside the vertex tensor (an out-of-range index yields NaN vertices and no gradient)."""
-    key = (faces.data_ptr(), faces._version, tuple(faces.shape), nv)
-    if _validated.get('key') == key:
+    """Range check of the face indices, for error reporting only: the kernels never read outside the vertex
+    tensor (an out-of-range index yields NaN vertices and no gradient).  One fused device-side reduction and a
+    single host read; skipped while a HIP graph is being captured (a host read is illegal there).  No cache: a
+    temporary index tensor can reuse the address and version of an earlier one."""
+    if faces.numel() == 0 or (faces.is_cuda and torch.cuda.is_current_stream_capturing()):
         return
-    if faces.numel() and (int(faces.min()) < 0 or int(faces.max()) >= nv):
+    lo, hi = torch.aminmax(faces)
+    if bool((lo < 0) | (hi >= nv)):
         raise IndexError('face index out of range')
-    _validated['key'] = key
 
 
 class ProjectFacesFunction(torch.autograd.Function):

@@ -27,17 +27,27 @@ class LaplacianLoss(nn.Module):
 
 
 class FlattenLoss(nn.Module):
-    """(cos(dihedral) + 1)^2 summed over interior edges."""
+    """(cos(dihedral) + 1)^2 summed over the reference's edge set (``gendr/losses.py:47-76``): the edges that
+    appear as index columns (0, 1) or (1, 2) of some face -- an interior edge that is the (2, 0) edge of BOTH
+    its faces is not in the set, exactly as in the reference.  For each edge, v2 / v3 are the opposite vertices of
+    the first / second face (in face order) that contains it.  Edges with a single adjacent face are skipped (the
+    reference's v2s / v3s lists fall out of step there)."""
 
     def __init__(self, faces, average=False):
         super().__init__()
         self.nf, self.average = faces.size(0), average
         f = faces.detach().cpu().numpy().astype(np.int64)
+        wanted = set()
+        for a, b in ((0, 1), (1, 2)):
+            for tri in f:
+                wanted.add((min(tri[a], tri[b]), max(tri[a], tri[b])))
         opposite = {}
         for tri in f:
             for a, b, c in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
-                opposite.setdefault((min(tri[a], tri[b]), max(tri[a], tri[b])), []).append(tri[c])
-        rows = [(e[0], e[1], o[0], o[1]) for e, o in opposite.items() if len(o) >= 2]
+                key = (min(tri[a], tri[b]), max(tri[a], tri[b]))
+                if key in wanted:
+                    opposite.setdefault(key, []).append(tri[c])
+        rows = [(e[0], e[1], o[0], o[1]) for e, o in sorted(opposite.items()) if len(o) >= 2]
         idx = np.asarray(rows, dtype=np.int64).reshape(-1, 4)
         for k, name in enumerate(('v0s', 'v1s', 'v2s', 'v3s')):
             self.register_buffer(name, torch.from_numpy(idx[:, k].copy()))

@@ -13,19 +13,29 @@ import parity
 TOL = 1e-5
 
 
-def noise_floor(fv, tex, image_size, opts, grad):
-    a = parity.run_oracle(fv, tex, image_size, opts, grad, np.float32)
+RAW_GRAD_KEYS = ('grad_faces', 'grad_textures')
+
+
+def noise_floor(fv, tex, image_size, opts, grad, oracle_f32=None):
+    """fp32-vs-fp64 spread of the oracle itself.  `oracle_f32`: an fp32 oracle run of the same inputs the caller
+    already has (parity.compare returns it), so that large frames are not evaluated twice."""
+    a = oracle_f32 if oracle_f32 is not None else parity.run_oracle(fv, tex, image_size, opts, grad, np.float32)
     b = parity.run_oracle(fv.astype(np.float64), tex.astype(np.float64), image_size, opts,
                           None if grad is None else grad.astype(np.float64), np.float64)
     out = dict(rgba=parity.stats(a['rgba'], b['rgba']), aggrs=parity.stats(a['aggrs_info'], b['aggrs_info']))
     if grad is not None:
         out['grad_faces_cond'] = parity.stats(a['grad_faces'], b['grad_faces'], scale=b['abs_faces'])
         out['grad_textures_cond'] = parity.stats(a['grad_textures'], b['grad_textures'], scale=b['abs_textures'])
+        out['grad_faces'] = parity.stats(a['grad_faces'], b['grad_faces'])
+        out['grad_textures'] = parity.stats(a['grad_textures'], b['grad_textures'])
     return out
 
 
-def check(res, noise, keys=('rgba', 'aggrs', 'grad_faces_cond', 'grad_textures_cond'), strict=False):
-    """Returns a list of failure strings (empty = pass)."""
+def check(res, noise, keys=('rgba', 'aggrs', 'grad_faces_cond', 'grad_textures_cond', 'grad_faces', 'grad_textures'), strict=False):
+    """Returns a list of failure strings (empty = pass).  The raw gradient tensors (error relative to |reference
+    element|, not to the sum of |contributions|) are held to the same rule on p99 and on the fraction above 1e-5;
+    their MAX is not asserted: one element whose contributions cancel to 1e-6 of their size moves by O(1) relative
+    with the summation order alone (the conditioned metric carries the max)."""
     bad = []
     for k in keys:
         if k not in res:
@@ -39,7 +49,7 @@ def check(res, noise, keys=('rgba', 'aggrs', 'grad_faces_cond', 'grad_textures_c
         n = noise[k]
         if e['p99_rel'] > max(TOL, 2 * n['p99_rel']):
             bad.append('%s: p99 %.2e vs fp32-noise p99 %.2e' % (k, e['p99_rel'], n['p99_rel']))
-        if e['max_rel'] > max(TOL, 2 * n['max_rel']):
+        if k not in RAW_GRAD_KEYS and e['max_rel'] > max(TOL, 2 * n['max_rel']):
             bad.append('%s: max %.2e vs fp32-noise max %.2e' % (k, e['max_rel'], n['max_rel']))
         if e['frac_gt_1e5'] > max(1e-3, 2 * n['frac_gt_1e5']):
             bad.append('%s: fraction>1e-5 %.2e vs fp32-noise %.2e' % (k, e['frac_gt_1e5'], n['frac_gt_1e5']))

@@ -30,6 +30,19 @@ def _worker(rank, world, port, out):
     (views * w).sum().backward()
     expect = 2.0 * torch.arange(18, dtype=torch.float32).reshape(6, 3)[rank * 3:rank * 3 + 3] * (1 + 2)
     assert torch.allclose(mine.grad, expect), (mine.grad, expect)
+    # unequal per-rank blocks must fail loudly on every rank instead of hanging / corrupting
+    try:
+        gather_views(torch.zeros(1 + rank, 2))
+        raise AssertionError('uneven blocks were accepted')
+    except ValueError:
+        pass
+    # the incoming gradient buffer is not reduced in place
+    x = torch.ones(2, 2, requires_grad=True)
+    upstream = torch.ones(4, 2)
+    keep = upstream.clone()
+    gather_views(x).backward(upstream)
+    assert torch.equal(upstream, keep) and torch.equal(x.grad, torch.full((2, 2), 2.0))
+    assert shard_range(6, group=dist.group.WORLD) == (rank * 3, rank * 3 + 3)
     g = torch.ones(4) * (rank + 1)
     sum_over_ranks(g)
     assert torch.equal(g, torch.full((4,), 3.0))
@@ -55,3 +68,34 @@ def test_shard_range_uneven():
     spans = [shard_range(10, r, 4) for r in range(4)]
     assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_range(5, 0, 1) == (0, 5)
+
+
+def test_bench_launcher_world2_stub():
+    """`bench.py --gpus 2` outside torchrun starts its own two ranks (gloo, stub step: no GPU here) and rank 0
+    prints one JSON line with n_gpus == 2, strong scaling of the global batch, plus the weak figure under extra."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--stub', '--batch', '6'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'strong' and j['steps'] == 3 and j['warmup'] == 1
+    assert j['config']['global_batch'] == 6 and j['extra']['weak']['global_batch'] == 12
+    assert j['value'] > 0 and j['unit'] == 'frames/s'
+
+
+def test_bench_refuses_world_mismatch():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--stub'],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and 'WORLD_SIZE' in (out.stderr + out.stdout)

@@ -55,6 +55,11 @@ def test_losses():
     assert close(lap(V), Z['laplacian_loss'], 1e-5)
     assert close(gendr_amd.LaplacianLoss(V[0], Fc[0].long(), average=True)(V), Z['laplacian_loss_avg'], 1e-5)
     assert close(gendr_amd.FlattenLoss(Fc[0].long())(V), Z['flatten_loss'], 1e-4)
+    # rotated index order: the reference drops edges that are (2,0) in both faces; same edge count, same loss
+    fr = torch.from_numpy(Z['faces_rotated'])
+    fl = gendr_amd.FlattenLoss(fr)
+    assert fl.v0s.shape[0] == int(Z['flatten_edges_rotated']) < 3 * fr.shape[0] // 2
+    assert close(fl(V), Z['flatten_loss_rotated'], 1e-4)
 
 
 def test_mesh_transform_chain_and_alias_package(tmp_path):

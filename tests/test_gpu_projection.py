@@ -170,3 +170,20 @@ def test_out_of_range_index_is_memory_safe_even_when_the_host_check_is_skipped()
     assert torch.isnan(out[1, 5, 2]).all() and torch.isfinite(out[0]).all() and torch.isfinite(out[1, 5, :2]).all()
     torch.nan_to_num(out).sum().backward()
     assert torch.isfinite(vv.grad).all()
+
+
+def test_broadcastable_eye_at_up_like_the_reference():
+    """A [1,3] eye / at / up broadcasts over the batch in the reference's look_at and in the unfused glue; the fused
+    path must accept it too (it raised ValueError)."""
+    v, f, _ = _inputs()
+    eye1 = torch.tensor([[0.3, 0.4, -2.7]], device='cuda')
+    up1 = torch.tensor([[0.0, 1.0, 0.0]], device='cuda')
+    out = Fn.look_at_faces(v, f, eye1, at=torch.zeros(1, 3, device='cuda'), up=up1, viewing_angle=20.)
+    unf = Fn.face_vertices(Fn.perspective(Fn.look_at(v, eye1, at=torch.zeros(1, 3, device='cuda'), up=up1), 20.), f)
+    np.testing.assert_allclose(out.cpu().numpy(), unf.cpu().numpy(), rtol=0, atol=TOL)
+    cam = gendr.LookAt(viewing_angle=20.)
+    cam.set_eyes(eye1)
+    m = gendr.Mesh(v, f)
+    np.testing.assert_allclose(cam(m).face_vertices.cpu().numpy(), unf.cpu().numpy(), rtol=0, atol=TOL)
+    with pytest.raises(ValueError):
+        Fn.look_at_faces(v, f, torch.zeros(2, 3, device='cuda'))        # genuinely incompatible: B = 3

@@ -106,3 +106,42 @@ def test_synthetic_scene_shape():
     fv, tex = benchmark_scene(3, subdivisions=1)
     assert fv.shape == (3, 80, 3, 3) and tex.shape == (3, 80, 1, 3)
     assert fv[..., :2].abs().max() < 1.0 and fv[..., 2].min() > 1.0
+
+
+def test_vec3_broadcast_rules():
+    from gendr_amd.functional.geometry import _as_vec3, look_at
+    assert _as_vec3([0, 0, 1], 'cpu', 4).shape == (4, 3)
+    assert _as_vec3(torch.zeros(1, 3), 'cpu', 4).shape == (4, 3)           # [1,3] broadcasts (reference behaviour)
+    assert _as_vec3(torch.zeros(4, 3), 'cpu', 4).shape == (4, 3)
+    assert _as_vec3(torch.zeros(2, 3), 'cpu', 4).shape == (2, 3)           # left to the caller's shape check
+    v = torch.rand(3, 5, 3)
+    a = look_at(v, torch.tensor([[0.0, 0.0, -2.7]]))
+    b = look_at(v, [0.0, 0.0, -2.7])
+    assert torch.equal(a, b)
+
+
+def test_cull_radius_is_an_upper_bound_for_every_distribution(native_lib):
+    """gendr_cull_radius bisects D(-x) against half the skip threshold; the bisection finds A crossing, culling
+    needs that NO outside pixel beyond the radius passes the reference's skip test (kernel.cu:784: D <= 1e-6), i.e.
+    D(-x) <= 1e-6 for every x >= r.  Scan that directly for every dist_func, scale, shape and shift -- it does not
+    rely on D(-x) being monotone (monotonicity only held empirically for the truncated gamma series)."""
+    import ctypes
+    import numpy as np
+    from gendr_amd.functional.renderer import make_params
+    L = native_lib
+    for tau in (1e-4, 1e-2, 3e-2, 1.0):
+        for fid in range(1, 18):
+            for squared in (False, True):
+                for shape, shift in ((0.0, 0.0), (0.5, 0.8), (1.5, 0.0), (2.0, 0.0), (2.0, 1.0), (3.5, 0.25)):
+                    p = make_params(64, [0, 0, 0], fid, tau, squared, shape, shift, 1e4, 2, 0.0, 1, 1e-3, 1e-3, 1, 100, True, 0)
+                    r = L.gendr_cull_radius(ctypes.byref(p))
+                    assert r == r and r >= 0
+                    r_eps = float(np.sqrt(np.float32(1e4) * np.float32(tau)))       # kernel.cu:769 cuts there anyway
+                    if not np.isfinite(r) or r >= r_eps:
+                        continue
+                    ds = np.unique(np.concatenate([r * (1 + np.logspace(-7, 1.5, 400)), np.linspace(r, min(r_eps, 4 * r + 1e-3), 400)]))
+                    for d in ds[ds < r_eps]:
+                        d = np.float32(d)
+                        x = float(d * d) if squared else float(d)
+                        v = L.gendr_sigmoid_forward(fid, -1.0, x, tau, shape, shift)
+                        assert v != v or v <= 1e-6, (fid, tau, squared, shape, shift, float(d), r, v)

@@ -129,6 +129,16 @@ def test_t_conorm_axioms_and_gradient(oracle_mod):
 
 
 def test_product_scalars_equal_oracle(oracle_mod, native_lib):
+    _product_scalars_equal_oracle(oracle_mod, native_lib)
+
+
+@pytest.mark.gpu
+def test_product_scalars_equal_oracle_on_the_gpu_box(oracle_mod, native_lib):
+    """Same sweep inside the -m gpu set, so that the driver's GPU run sees SURVEY row a15 exhaustively."""
+    _product_scalars_equal_oracle(oracle_mod, native_lib)
+
+
+def _product_scalars_equal_oracle(oracle_mod, native_lib):
     """The host-callable exports of libgendr_hip.so (same source as the device code) against the oracle's
     float instantiation.  Both run on glibc here, so they must agree bit for bit."""
     rs = np.random.RandomState(1)
