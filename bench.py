@@ -93,24 +93,39 @@ def cpu_baseline_oracle(cfg, fv, tex, target_seconds=12.0):
                        % (n, isz, isz, fvn.shape[1], cores, tn))
 
 
-def _torch_baseline_worker(q, cfg, fv, tex, stride, threads):
-    import torch
-    from oracle import torch_ref
-    torch.set_num_threads(threads)
-    opts = dict(cfg['opts'])
-    opts.setdefault('double_side', False)
-    isz = cfg['image_size']
-    g = torch.randn(1, 4, isz, isz, generator=torch.Generator().manual_seed(1))
-    t0 = time.perf_counter()
-    torch_ref.render(fv[:1, ::stride].contiguous(), tex[:1, ::stride].contiguous(), isz, grad=g, **opts)
-    q.put(time.perf_counter() - t0)
+def _torch_baseline_worker(q, cfg, fv, tex, stride, threads, budget):
+    """Child process: times 1 frame on every `stride`-th face; starts from a coarse sample and refines while the
+    projected time fits the budget.  Puts (seconds, stride) or ('error', text)."""
+    try:
+        import torch
+        from oracle import torch_ref
+        torch.set_num_threads(threads)
+        opts = dict(cfg['opts'])
+        opts.setdefault('double_side', False)
+        isz = cfg['image_size']
+        g = torch.randn(1, 4, isz, isz, generator=torch.Generator().manual_seed(1))
+
+        def run(st):
+            t0 = time.perf_counter()
+            torch_ref.render(fv[:1, ::st].contiguous(), tex[:1, ::st].contiguous(), isz, grad=g, **opts)
+            return time.perf_counter() - t0
+
+        st = max(stride, 16)
+        dt = run(st)
+        while st > stride and dt * 2.2 < budget:
+            st //= 2
+            dt = run(st)
+        q.put((dt, st))
+    except Exception as e:      # reported in the JSON line instead of vanishing with the child
+        q.put(('error', '%s: %s' % (type(e).__name__, e)))
 
 
-def cpu_baseline_torch(cfg, fv, tex, stride=4, timeout=150):
+def cpu_baseline_torch(cfg, fv, tex, stride=4, timeout=200, budget=25.0):
     """The pure-PyTorch evaluation of the same per-pixel math (oracle/torch_ref.py) that BASELINE.json's
     north_star asks for next to the GPU number, on ALL host cores.  It evaluates every (pixel, face) pair, so its
-    cost is linear in the face count: a BOUNDED sample (1 frame, every `stride`-th face) is timed in a child
-    process with a hard timeout and scaled by `stride`.  Only for option sets the restatement covers."""
+    cost is linear in the face count: a BOUNDED sample (1 frame, every k-th face, k chosen so that the sample takes
+    about `budget` seconds at most) is timed in a child process with a hard timeout and scaled by k.  Only for
+    option sets the restatement covers.  Returns a dict; on failure a dict with 'error'."""
     import multiprocessing as mp
     from oracle import torch_ref
     opts = cfg['opts']
@@ -119,24 +134,23 @@ def cpu_baseline_torch(cfg, fv, tex, stride=4, timeout=150):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     threads = max(1, os.cpu_count() or 1)
-    isz = cfg['image_size']
-    while stride < 64 and isz * isz * (fv.shape[1] // stride) > 40e6:      # bound the sample for the large configs
-        stride *= 2
-    p = ctx.Process(target=_torch_baseline_worker, args=(q, cfg, fv[:1].cpu(), tex[:1].cpu(), stride, threads))
+    p = ctx.Process(target=_torch_baseline_worker, args=(q, cfg, fv[:1].cpu(), tex[:1].cpu(), stride, threads, budget))
     p.start()
     p.join(timeout)
     if p.is_alive():
         p.kill()
         p.join()
-        return None
+        return dict(error='pure-PyTorch baseline exceeded its %d s limit' % timeout)
     if q.empty():
-        return None
-    dt = q.get() * stride
+        return dict(error='pure-PyTorch baseline child exited with code %s' % p.exitcode)
+    dt, st = q.get()
+    if dt == 'error':
+        return dict(error=st)
     nf = fv.shape[1]
-    return dict(value=1.0 / dt, unit='frames/s', cores=threads, kind='port',
+    return dict(value=1.0 / (dt * st), unit='frames/s', cores=threads, kind='port',
                 sample='1 frame, every %dth of the %d faces (all-pairs evaluation, linear in faces), forward+backward, '
                        'vectorised pure PyTorch (oracle/torch_ref.py), torch.set_num_threads(%d) = all host cores; %.1f s scaled x%d'
-                       % (stride, nf, threads, dt / stride, stride))
+                       % (st, nf, threads, dt, st))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -446,13 +460,14 @@ def main():
             out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline and not args.stub:
             nb = min(B, 64)
-            oc = cpu_baseline_oracle(cfg, wl.fv_cpu[:nb], wl.tex_cpu[:nb])
             tb = cpu_baseline_torch(cfg, wl.fv_cpu[:nb], wl.tex_cpu[:nb])
-            if tb is not None:
+            oc = cpu_baseline_oracle(cfg, wl.fv_cpu[:nb], wl.tex_cpu[:nb])
+            if tb is not None and 'error' not in tb:
                 out['cpu_baseline'] = tb
                 out['cpu_baseline_oracle'] = oc
             else:
-                oc['note'] = 'oracle/torch_ref.py does not cover this option set; C/OpenMP oracle instead'
+                oc['note'] = ('pure-PyTorch baseline failed (%s); C/OpenMP oracle instead' % tb['error']) if tb else \
+                             'oracle/torch_ref.py does not cover this option set; C/OpenMP oracle instead'
                 out['cpu_baseline'] = oc
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -30,21 +30,18 @@ typedef void (*render_kernel_t)(const RenderArgs);
 // scripts get their own kernel (only their own CDF / t-conorm branch is compiled in); everything else runs
 // the runtime-dispatch kernel of its texture mode, which carries all 18 x 10 branches.
 struct KernelKey { int dist, alpha, rgb, sq, texm; };
-struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd, bwd_wide; };   // bwd_wide: eight-faces-per-step phase A
+struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; };
 
 #define GENDR_SPECIALISE(D, A, RGB, SQ, TEXM) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM, 0>, \
-      render_backward_kernel<D, A, RGB, SQ, TEXM, 1> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM> }
 
 // same, with the register budget capped for 6 (forward) / 5 (backward) waves per SIMD
 #define GENDR_SPECIALISE_OCC(D, A, RGB, SQ, TEXM) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM, 0>, \
-      render_backward_kernel_w5<D, A, RGB, SQ, TEXM, 1> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM> }
 
 // same with explicit register-budget suffixes for the forward / backward kernels (_wl 5/4, _wa 4, _wf 2 waves per SIMD)
 #define GENDR_SPECIALISE_K2(D, A, RGB, SQ, TEXM, KF, KB) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_##KF<D, A, RGB, SQ, TEXM>, render_backward_kernel_##KB<D, A, RGB, SQ, TEXM, 0>, \
-      render_backward_kernel_##KB<D, A, RGB, SQ, TEXM, 1> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_##KF<D, A, RGB, SQ, TEXM>, render_backward_kernel_##KB<D, A, RGB, SQ, TEXM> }
 #define GENDR_SPECIALISE_K(D, A, RGB, SQ, TEXM, KF, KB) GENDR_SPECIALISE_K2(D, A, RGB, SQ, TEXM, KF, KB)
 
 #ifndef C2B
@@ -71,8 +68,7 @@ const KernelEntry kSpecialised[] = {
 // (register budget): _wl light x light, _wa light distributions x all aggregators, _wf whenever the heavy
 // distributions are compiled in (their register need does not fit more than two waves per SIMD without heavy spills).
 #define GENDR_GENERIC_ROW(D, A, TEXM, K) \
-    { {D, A, -1, -1, TEXM}, render_forward_kernel_##K<D, A, -1, -1, TEXM>, render_backward_kernel_##K<D, A, -1, -1, TEXM, 0>, \
-      render_backward_kernel_##K<D, A, -1, -1, TEXM, 1> }
+    { {D, A, -1, -1, TEXM}, render_forward_kernel_##K<D, A, -1, -1, TEXM>, render_backward_kernel_##K<D, A, -1, -1, TEXM> }
 #define GENDR_GENERIC_CLASS(D, A, K) \
     { GENDR_GENERIC_ROW(D, A, kTexSurface1, K), GENDR_GENERIC_ROW(D, A, kTexVertex, K), GENDR_GENERIC_ROW(D, A, kTexSurfaceN, K) }
 
@@ -95,12 +91,26 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm)
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t boxes_off, records_off, masks_off, lists_off, control_off, total;
+    size_t boxes_off, records_off, masks_off, lists_off, tileoff_off, tilecnt_off, entries_off, control_off, total;
     int tiles_x, chunks, supers_x, ncontrol;
+    long ent_cap8;
 };
 
-// workspace layout: [cull boxes B*nf*4 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
-//                   [tile queues B*tiles i32][control: queue lengths]
+// Entry pool (CoverEnt, 16 bytes each): every listed (tile, face) gets a slot, so the worst case is tiles * nf.  Sized
+// for 32 listings per tile plus 64 per face -- several times what the configs of BASELINE.json list (C2 5.7 per tile,
+// C4 31 per tile / 100 per face, C5 144 per face) -- and never more than the worst case; a tile that finds the pool
+// exhausted is still rendered exactly (tile_off = -1: the render kernels apply the per-pixel tests themselves).
+long entry_capacity(long B, long tiles, long nf)
+{
+    const long worst = B * tiles * nf;
+    long want = 32 * B * tiles + 64 * B * nf;
+    if (want > worst) want = worst;
+    if (want > 0x7fffff00L) want = 0x7fffff00L;          // entry offsets are ints
+    return (want + 7) / 8 * 8;
+}
+
+// workspace layout: [bin records B*nf*16 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
+//                   [tile queues B*tiles i32][tile_off B*tiles i32][tile_cnt B*tiles i32][entry pool][control counters]
 Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
 {
     Workspace w;
@@ -108,11 +118,16 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.tiles_x = (p->image_size + kTile - 1) / kTile;
     w.chunks = (nf + 63) / 64;
     w.supers_x = (w.tiles_x + 7) / 8;
+    const size_t tiles = (size_t)B * w.tiles_x * w.tiles_x;
+    w.ent_cap8 = entry_capacity(B, (long)w.tiles_x * w.tiles_x, nf) / 8;
     w.boxes_off = 0;
-    w.records_off = align256((size_t)B * nf * 4 * sizeof(float));
+    w.records_off = align256((size_t)B * nf * kBinRec * sizeof(float));
     w.masks_off = w.records_off + align256((size_t)B * nf * record_floats(texm) * sizeof(float));
-    w.lists_off = w.masks_off + align256((size_t)B * w.tiles_x * w.tiles_x * w.chunks * sizeof(unsigned long long));
-    w.control_off = w.lists_off + align256((size_t)B * w.tiles_x * w.tiles_x * sizeof(int));
+    w.lists_off = w.masks_off + align256(tiles * w.chunks * sizeof(unsigned long long));
+    w.tileoff_off = w.lists_off + align256(tiles * sizeof(int));
+    w.tilecnt_off = w.tileoff_off + align256(tiles * sizeof(int));
+    w.entries_off = w.tilecnt_off + align256(tiles * sizeof(int));
+    w.control_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
     w.ncontrol = kCtlInts;
     w.total = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
     return w;
@@ -127,6 +142,10 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + w.masks_off);
     a.tile_list = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.lists_off);
     a.control = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.control_off);
+    a.tile_off = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.tileoff_off);
+    a.tile_cnt = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.tilecnt_off);
+    a.entries = reinterpret_cast<CoverEnt*>(static_cast<char*>(const_cast<void*>(workspace)) + w.entries_off);
+    a.ent_cap8 = w.ent_cap8;
     a.textures = textures;
     a.B = B; a.nf = nf; a.T = T;
     a.R = (int)sqrt((double)T);                                  // kernel.cu:1098
@@ -143,6 +162,7 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.r_gamma = 1. / (double)p->aggr_rgb_gamma;
     a.r_zrange = 1. / (double)(p->far_ - p->near_);              // float subtraction first, as kernel.cu:826
     a.r_nzrange = 1. / (double)(p->near_ - p->far_);             // kernel.cu:1026
+    a.r_is = 1. / (double)p->image_size;
     return texm;
 }
 
@@ -318,6 +338,15 @@ float gendr_cull_radius(const gendr_params* p)
     return r;
 }
 
+int gendr_selftest(int what, unsigned long long* report16, void* stream)
+{
+    if (!report16) return GENDR_E_NULL;
+    if (what < 0 || what > 2) return GENDR_E_SHAPE;
+    if (hipMemsetAsync(report16, 0, 16 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return GENDR_E_LAUNCH;
+    hipLaunchKernelGGL(selftest_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, what, report16);
+    return check_launch();
+}
+
 int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* stream)
 {
     if (!faces || !faces_info) return GENDR_E_NULL;
@@ -363,6 +392,13 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     const long bblocks = (long)B * w.supers_x * w.supers_x;
     if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
     hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kBinThreads), 0, s, boxes, a, w.supers_x, p->cull);
+    e = check_launch();
+    if (e != GENDR_OK) return e;
+    // coverage entries of the listed tiles: one wave per queue slot, same walk as the render kernels
+    const int cblocks = render_blocks(a.total_blocks);
+    if (texm == kTexSurface1)    hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurface1)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+    else if (texm == kTexVertex) hipLaunchKernelGGL(cover_kernel<record_floats(kTexVertex)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+    else                         hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurfaceN)>, dim3(cblocks), dim3(kThreads), 0, s, a);
     return check_launch();
 }
 
@@ -407,11 +443,7 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.grad_textures = grad_textures;
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
-    // Phase A of backward examines eight faces side by side when tiles list many faces, i.e. when faces are small
-    // next to an 8x8 tile; the host only knows image size and face count, which is a fair proxy: below 400 pixels of
-    // image per face (C2: 51, C4: 205, C5 at 2048^2: 3277) the wide walk is used.
-    const bool wide = (long)p->image_size * p->image_size < 400L * nf;
-    hipLaunchKernelGGL(wide ? k.bwd_wide : k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

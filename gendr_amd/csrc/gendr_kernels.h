@@ -12,10 +12,12 @@
 //     box outside of which the reference itself would skip the pair (kernel.cu:747,769,784); the binning kernel
 //     tests those boxes against every tile rectangle, leaves one bit per (tile, face) in HBM -- ascending face order
 //     for free, shared by forward and backward -- and queues the tiles that list anything (8 queues, one per XCD);
-//   * the render kernels walk those queues.  Per tile: phase A finds the (pixel, face) pairs that survive the exact
-//     per-pixel tests (forward: lane = pixel, face record in SGPRs via scalar loads; backward: eight faces per step,
-//     lane = (face, pixel row), records by vector gathers) and appends them to a wave-private LDS list;
-//     phase B runs dense -- lane = pair -- over batches of 64 pairs: distance, CDF, depth, colour (+ gradients);
+//   * the coverage kernel (one wave per listed tile, eight faces per step, lane = (face, pixel row)) applies the exact
+//     per-pixel tests once and leaves, per tile, the list of (face, 64-bit pixel mask) entries that own at least one
+//     pixel -- shared by forward and backward, so neither render kernel looks at a face record before it has to;
+//   * the render kernels walk the tile queues.  Per tile they read the entry list (one coalesced load per 64 entries),
+//     append the (pixel, face) pairs to a wave-private LDS list and run
+//     phase B dense -- lane = pair -- over batches of 64 pairs: distance, CDF, depth, colour (+ gradients);
 //     phase C (forward) folds the results per pixel in ascending face order, so the alpha fold and the online
 //     softmax keep the reference's order without any cross-lane combination; backward instead sums each face's
 //     partials over its pairs from a padded LDS matrix and issues one hardware fp32 atomic per (batch, face,
@@ -63,6 +65,10 @@
 
 #ifndef GENDR_SPLIT_MIN
 #define GENDR_SPLIT_MIN 8
+#endif
+
+#ifndef GENDR_BIN_EDGE
+#define GENDR_BIN_EDGE 0   // 1: the binning kernel also applies the exact per-(face, tile) edge test (see bin_faces_kernel)
 #endif
 
 #ifndef GENDR_ABLATE
@@ -159,7 +165,16 @@ constexpr int kSplitMin = GENDR_SPLIT_MIN;   // a face's pairs are split over tw
 // the 8 XCDs, so the waves of workgroups with blockIdx.x & 7 == x walk queue x: the tiles of an image (band) are
 // rendered through one XCD's L2, which then holds that image's face records and mask rows once.  (If the dispatch
 // order were different every tile would still be rendered exactly once; only the locality would suffer.)
-constexpr int kCtlStride = 1024, kCtlInts = 16 * kCtlStride;
+//   [(16 + x) * kCtlStride]        : entries allocated so far in region x of the entry pool (bin_faces_kernel).
+constexpr int kCtlStride = 1024, kCtlInts = 24 * kCtlStride;
+
+// Per-face record of the binning kernel (floats): the cull box, then for each edge k the row (a, b, c) of the
+// barycentric matrix and wcull_k -- what the exact per-(face, tile) edge test needs, 64 bytes per face, coalesced.
+constexpr int kBinRec = 16;
+
+// One entry of a tile's coverage list: face index and the ballot of the tile's pixels that pass the exact box / edge
+// tests for it (bit p = pixel lane p).  Written by cover_kernel, read by both render kernels.
+struct __attribute__((aligned(16))) CoverEnt { int fn; int npix; unsigned lo, hi; };
 
 __device__ __forceinline__ long queue_begin(int x, long n_tiles) { return ((long)x * n_tiles) >> 3; }
 // the x with queue_begin(x) <= g < queue_begin(x + 1)
@@ -176,6 +191,11 @@ struct RenderArgs {
     float*        grad_textures;
     int*          tile_list;    // [B * tiles_per_image]: 8 queues of global tile ids, see kCtlInts
     int*          control;      // queue lengths
+    CoverEnt*     entries;      // entry pool: 8 regions of ent_cap8 entries (one per tile queue)
+    int*          tile_off;     // [B * tiles_per_image]: first entry of the tile, or -1 (pool exhausted: the render
+                                //   kernels then run the per-pixel tests themselves, from the mask row)
+    int*          tile_cnt;     // [B * tiles_per_image]: number of entries (faces that own a pixel of the tile)
+    long          ent_cap8;     // capacity of one region of the entry pool
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
     gendr_params p;
@@ -186,6 +206,7 @@ struct RenderArgs {
     double r_gamma;             // 1 / aggr_rgb_gamma
     double r_zrange;            // 1 / (far - near)        (kernel.cu:826)
     double r_nzrange;           // 1 / (near - far)        (kernel.cu:1026)
+    double r_is;                // 1 / image_size          (kernel.cu:718-719)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -239,7 +260,7 @@ __device__ __forceinline__ float round_down(double v)
     return f;
 }
 
-// One thread per face.  Writes boxes[i][4] and records[i][REC].
+// One thread per face.  Writes boxes[i][kBinRec] (the binning kernel's record) and records[i][REC].
 //   sthr   = sqrtf(dist_eps * dist_scale), the reference's border margin (:747)
 //   cull_r = distance beyond which an outside pixel contributes nothing (gendr_cull_radius), or +inf
 template <int TEXM>
@@ -324,39 +345,50 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         }
     }
 
-    float4* b4 = reinterpret_cast<float4*>(boxes + i * 4);
-    *b4 = make_float4(xlo, xhi, ylo, yhi);
+    // bin record: box, then (a, b, c, wcull) per edge.  The edge test is only handed over when the three coefficients are
+    // finite (a tile-corner evaluation of an infinite coefficient times a zero pixel coordinate would not bound the
+    // per-pixel value, which is NaN there and never rejected).
+    float4* b4 = reinterpret_cast<float4*>(boxes + i * kBinRec);
+    b4[0] = make_float4(xlo, xhi, ylo, yhi);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float a = g.inv[3 * k], b = g.inv[3 * k + 1], c = g.inv[3 * k + 2];
+        const bool finite = fabsf(a) < INFINITY && fabsf(b) < INFINITY && fabsf(c) < INFINITY;
+        b4[1 + k] = make_float4(a, b, c, finite ? wcull[k] : -INFINITY);
+    }
 
-    float* r = records + i * REC;
+    // the record leaves in 16-byte stores (REC is a multiple of 4 floats)
+    float r[REC];
+#pragma unroll
+    for (int k = 0; k < REC; k++) r[k] = 0.f;
     r[kRecBox + 0] = xlo; r[kRecBox + 1] = xhi; r[kRecBox + 2] = ylo; r[kRecBox + 3] = yhi;
 #pragma unroll
     for (int k = 0; k < 9; k++) r[kRecInv + k] = g.inv[k];
     r[kRecBits] = __int_as_float(g.obt | (g.front << 3));
     r[kRecWCull + 0] = wcull[0]; r[kRecWCull + 1] = wcull[1]; r[kRecWCull + 2] = wcull[2];
-    r[17] = 0.f; r[18] = 0.f; r[19] = 0.f;
-    double* rden = reinterpret_cast<double*>(r + kRecRDen);
-    double* rz = reinterpret_cast<double*>(r + kRecRZ);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int k1 = (k + 1) % 3;
         float a[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) { a[j] = g.sym[3 * k + j] - g.sym[3 * k1 + j]; r[kRecEdge + 3 * k + j] = a[j]; }
-        rden[k] = 1. / (double)(a[k] - a[k1]);
+        const double rden = 1. / (double)(a[k] - a[k1]);
+        r[kRecRDen + 2 * k] = __int_as_float(__double2loint(rden)); r[kRecRDen + 2 * k + 1] = __int_as_float(__double2hiint(rden));
         r[kRecXY + 2 * k] = f[3 * k]; r[kRecXY + 2 * k + 1] = f[3 * k + 1];
-        rz[k] = 1. / (double)f[3 * k + 2];
+        const double rz = 1. / (double)f[3 * k + 2];
+        r[kRecRZ + 2 * k] = __int_as_float(__double2loint(rz)); r[kRecRZ + 2 * k + 1] = __int_as_float(__double2hiint(rz));
     }
-    r[29] = 0.f;
     if (TEXM == kTexSurface1) {
         const long nxt = (i + 1 < total_faces) ? i + 1 : i;   // reference reads the next face's texel (:179-182); none after the last
 #pragma unroll
         for (int k = 0; k < 3; k++) { r[kRecTex + k] = textures[i * 3 + k]; r[kRecTex + 3 + k] = textures[nxt * 3 + k]; }
-        r[kRecTex + 6] = 0.f; r[kRecTex + 7] = 0.f;
     } else if (TEXM == kTexVertex) {
 #pragma unroll
         for (int k = 0; k < 9; k++) r[kRecTex + k] = textures[i * 9 + k];
-        r[kRecTex + 9] = 0.f; r[kRecTex + 10] = 0.f; r[kRecTex + 11] = 0.f;
     }
+    float4* out4 = reinterpret_cast<float4*>(records + i * REC);
+#pragma unroll
+    for (int q = 0; q < REC / 4; q++) out4[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
 }
 
 // faces_info in the reference's own layout [B*nf][27] (kernel.cu:620-676)
@@ -384,9 +416,9 @@ __global__ __launch_bounds__(kThreads) void face_info_kernel(const float* __rest
 // (2.*idx + 1. - is) / is of kernel.cu:718-719.  The reference evaluates it in double and rounds to float;
 // numerator and denominator are integers below 2^24, so the float division rounds to the same value
 // (and div_by() reproduces that float division exactly).
-__device__ __forceinline__ float pixel_coord(int idx, int is)
+__device__ __forceinline__ float pixel_coord(int idx, int is, double r_is)
 {
-    return div_by((float)(2 * idx + 1 - is), 1. / (double)is);   // 1/is folds to a wave-uniform constant
+    return div_by((float)(2 * idx + 1 - is), r_is);              // r_is = RN(1 / (double)is), computed once on the host
 }
 
 // box = (xlo, xhi, ylo, yhi).  A rectangle of pixel centres misses the box iff every centre fails the
@@ -412,6 +444,42 @@ constexpr int kBinThreads = GENDR_BIN_THREADS, kBinWaves = kBinThreads / 64;
 constexpr int kBinGroup = 32;      // chunks staged in LDS per round
 constexpr int kBinLoopMax = GENDR_BIN_LOOP_MAX;   // up to this many candidate faces of a chunk are broadcast one by one
 
+struct BinFace { float4 box, e0, e1, e2; };      // one face's bin record in registers
+
+// Exact per-(face, tile) edge test.  The per-pixel test of the loop rejects a pixel whose COMPUTED barycentric
+// w_k = a*xp + b*yp + c (this very float expression, kernel.cu:39-43) is below wcull_k.  Float multiplication and
+// addition are monotone, so over the tile's grid of pixel centres the computed w_k is largest at the corner pixel
+// picked by the signs of a and b: if even that value is below wcull_k, every pixel of the tile fails the test and the
+// face need not be listed.  No error analysis involved -- the tile test evaluates the pixel test's own arithmetic.
+__device__ __forceinline__ bool edge_rejects_tile(const float4& e, float rx_lo, float rx_hi, float ry_lo, float ry_hi)
+{
+    const float cx = e.x >= 0.f ? rx_hi : rx_lo;
+    const float cy = e.y >= 0.f ? ry_hi : ry_lo;
+    const float w = e.x * cx + e.y * cy + e.z;
+    return w < e.w;
+}
+__device__ __forceinline__ bool face_meets_tile(const BinFace& f, float rx_lo, float rx_hi, float ry_lo, float ry_hi)
+{
+    return rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, f.box) &&
+           !(edge_rejects_tile(f.e0, rx_lo, rx_hi, ry_lo, ry_hi) || edge_rejects_tile(f.e1, rx_lo, rx_hi, ry_lo, ry_hi) ||
+             edge_rejects_tile(f.e2, rx_lo, rx_hi, ry_lo, ry_hi));
+}
+__device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float4 bcast4(const float4& v, int l) { return make_float4(bcast(v.x, l), bcast(v.y, l), bcast(v.z, l), bcast(v.w, l)); }
+
+__device__ __forceinline__ int wave_exclusive_scan(int v, int& total)
+{
+    const int lane = threadIdx.x & 63;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    total = __builtin_amdgcn_readlane(incl, 63);
+    return incl - v;
+}
+
 __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
 {
     __shared__ unsigned long long s_words[64][kBinGroup + 1];
@@ -426,45 +494,66 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
     // lane t owns tile t of the super-tile: its rectangle and, at the end, its mask words
     const int ty_l = sy * 8 + (lane >> 3), tx_l = sx * 8 + (lane & 7);
     const bool tile_ok = ty_l < tiles_x && tx_l < tiles_x;
-    const float rx_lo = pixel_coord(tx_l * 8, is), rx_hi = pixel_coord(min(tx_l * 8 + 7, is - 1), is);
-    const float ry_hi = pixel_coord(is - 1 - ty_l * 8, is), ry_lo = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is);
-    const float sx_lo = pixel_coord(sx * 64, is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is);
-    const float sy_hi = pixel_coord(is - 1 - sy * 64, is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is);
+    const float rx_lo = pixel_coord(tx_l * 8, is, a.r_is), rx_hi = pixel_coord(min(tx_l * 8 + 7, is - 1), is, a.r_is);
+    const float ry_hi = pixel_coord(is - 1 - ty_l * 8, is, a.r_is), ry_lo = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is, a.r_is);
+    const float sx_lo = pixel_coord(sx * 64, is, a.r_is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is, a.r_is);
+    const float sy_hi = pixel_coord(is - 1 - sy * 64, is, a.r_is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is, a.r_is);
     const long tile_base = (long)b * a.tiles_per_image;
-    unsigned long long seen = 0ull;                                          // first wavefront: OR of this tile's words
+    int listed_faces = 0;                                                    // first wavefront: faces listed for this lane's tile
 
     for (int c0 = 0; c0 < chunks; c0 += kBinGroup) {
         const int ng = min(kBinGroup, chunks - c0);
-        // this wavefront's chunks of the round: all box loads first (one memory round trip instead of one per chunk)
         constexpr int kPerWave = (kBinGroup + kBinWaves - 1) / kBinWaves;
-        float4 boxes_w[kPerWave];
-#pragma unroll
-        for (int u = 0; u < kPerWave; u++) {
-            const int ci = wave + u * kBinWaves;
-            const int fi = (c0 + ci) * 64 + lane;
-            boxes_w[u] = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
-            if (ci < ng && fi < a.nf) boxes_w[u] = reinterpret_cast<const float4*>(boxes)[(long)b * a.nf + fi];
-        }
 #pragma unroll
         for (int u = 0; u < kPerWave; u++) {
             const int ci = wave + u * kBinWaves;
             if (ci >= ng) break;
-            const float4 box = boxes_w[u];
-            const bool have = (c0 + ci) * 64 + lane < a.nf;
+            const int fi = (c0 + ci) * 64 + lane;
+            const bool have = fi < a.nf;
+            BinFace f;
+            f.box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
+            f.e0 = f.e1 = f.e2 = make_float4(0.f, 0.f, 0.f, -INFINITY);
+            if (have) {
+                const float4* src = reinterpret_cast<const float4*>(boxes) + ((long)b * a.nf + fi) * (kBinRec / 4);
+                f.box = src[0];
+#if GENDR_BIN_EDGE
+                f.e0 = src[1]; f.e1 = src[2]; f.e2 = src[3];
+#endif
+            }
             unsigned long long mine = 0ull;
-            // faces of the chunk whose box meets the super-tile at all
+#if GENDR_BIN_EDGE
+            // faces of the chunk that meet the super-tile at all (same exact test on the super-tile's rectangle)
+            unsigned long long cand = __ballot(have && (cull ? face_meets_tile(f, sx_lo, sx_hi, sy_lo, sy_hi) : true));
+            if (__popcll(cand) <= kBinLoopMax) {
+                // a handful: broadcast each face's record, every tile lane sets its bit
+                while (cand) {
+                    const int l = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    BinFace fb;
+                    fb.box = bcast4(f.box, l); fb.e0 = bcast4(f.e0, l); fb.e1 = bcast4(f.e1, l); fb.e2 = bcast4(f.e2, l);
+                    if (cull ? face_meets_tile(fb, rx_lo, rx_hi, ry_lo, ry_hi) : true) mine |= 1ull << l;
+                }
+            } else {
+                // many (the super-tiles under the object): one ballot over the face lanes per tile
+                const bool is_cand = (cand >> lane) & 1ull;
+                for (int tl = 0; tl < 64; tl++) {
+                    const float tx_lo = bcast(rx_lo, tl), tx_hi = bcast(rx_hi, tl), ty_lo = bcast(ry_lo, tl), ty_hi = bcast(ry_hi, tl);
+                    const unsigned long long word = __ballot(is_cand && (cull ? face_meets_tile(f, tx_lo, tx_hi, ty_lo, ty_hi) : true));
+                    if (lane == tl) mine = word;
+                }
+            }
+#else
+            // Box test only (measured: the exact per-(face, tile) edge test above removes a third of the listings but
+            // costs this kernel 43 us at C2; the coverage kernel drops those faces for 10 us).
+            const float4 box = f.box;
             unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
             if (__popcll(cand) <= kBinLoopMax) {
                 // a handful: broadcast each box, every tile lane sets its bit
                 while (cand) {
-                    const int f = __builtin_ctzll(cand);
+                    const int l = __builtin_ctzll(cand);
                     cand &= cand - 1;
-                    float4 fb;
-                    fb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.x), f));
-                    fb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.y), f));
-                    fb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.z), f));
-                    fb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(box.w), f));
-                    if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << f;
+                    const float4 fb = bcast4(box, l);
+                    if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << l;
                 }
             } else {
                 // many (the super-tiles under the object): the same predicate is separable, so every face lane marks
@@ -473,10 +562,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     // column k's x-range is held by lane k (row 0), row k's y-range by lane 8k (column 0)
-                    const float cx_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_lo), k));
-                    const float cx_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx_hi), k));
-                    const float cy_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_lo), 8 * k));
-                    const float cy_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry_hi), 8 * k));
+                    const float cx_lo = bcast(rx_lo, k), cx_hi = bcast(rx_hi, k), cy_lo = bcast(ry_lo, 8 * k), cy_hi = bcast(ry_hi, 8 * k);
                     const bool hx = cull ? !(cx_lo > box.y || cx_hi < box.x) : true;
                     const bool hy = cull ? !(cy_lo > box.w || cy_hi < box.z) : true;
                     mx |= (hx ? 1u : 0u) << k;
@@ -489,6 +575,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
                     if (lane == tl) mine = word;
                 }
             }
+#endif
             s_words[lane][ci] = mine;
         }
         __syncthreads();
@@ -499,29 +586,39 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
                 const_cast<unsigned long long*>(a.masks)[(tile_base + (long)ty * tiles_x + tx) * chunks + c0 + ci] = s_words[tl][ci];
         }
         if (wave == 0)
-            for (int ci = 0; ci < ng; ci++) seen |= s_words[lane][ci];
+            for (int ci = 0; ci < ng; ci++) listed_faces += __popcll(s_words[lane][ci]);
         __syncthreads();
     }
     if (wave != 0) return;
 
-    // tile queues.  Usually the 64 tiles belong to one queue; small batches of small images put several into one wave
+    // tile queues and the tiles' slices of the entry pool.  Usually the 64 tiles belong to one queue; small batches
+    // of small images put several into one wave
     const long g = tile_base + (long)ty_l * tiles_x + tx_l;
     const int xq = tile_ok ? queue_of_tile(g, a.total_tiles) : -1;
+    if (!tile_ok) listed_faces = 0;
     unsigned long long todo = __ballot(tile_ok);
     while (todo) {
         const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
         const unsigned long long mine = __ballot(xq == x);
         todo &= ~mine;
-        const unsigned long long listed = __ballot(xq == x && seen != 0ull);
+        const unsigned long long listed = __ballot(xq == x && listed_faces != 0);
         const unsigned long long empty = mine & ~listed;
-        int base_l = 0, base_e = 0;
+        int need = 0;
+        const int before = wave_exclusive_scan(xq == x ? listed_faces : 0, need);
+        int base_l = 0, base_e = 0, base_n = 0;
         if (lane == 0) {
             if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
             if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
+            if (need)   base_n = atomicAdd(a.control + (16 + x) * kCtlStride, need);
         }
         base_l = __builtin_amdgcn_readfirstlane(base_l);
         base_e = __builtin_amdgcn_readfirstlane(base_e);
-        if ((listed >> lane) & 1ull) a.tile_list[queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt)] = (int)g;
+        base_n = __builtin_amdgcn_readfirstlane(base_n);
+        if ((listed >> lane) & 1ull) {
+            a.tile_list[queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt)] = (int)g;
+            const long at = (long)base_n + before;                              // inside region x of the pool
+            a.tile_off[g] = (at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL) ? (int)((long)x * a.ent_cap8 + at) : -1;
+        }
         if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
     }
 }
@@ -538,15 +635,6 @@ struct TileCtx {
     float xp, yp;       // pixel centre, kernel.cu:716-719
     long  pix;          // row * is + xi
 };
-
-// pixel centre of lane `pl` of the tile whose lane `lane` is this thread (same arithmetic as tile_setup)
-__device__ __forceinline__ void pair_pixel(float& xp, float& yp, const TileCtx& t, int pl, int is)
-{
-    const int lane = threadIdx.x & 63;
-    const int xi = t.xi - (lane & 7) + (pl & 7), row = t.row - (lane >> 3) + (pl >> 3);
-    xp = pixel_coord(xi, is);
-    yp = pixel_coord(is - 1 - row, is);
-}
 
 // The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
 // own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
@@ -577,8 +665,8 @@ __device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int 
     t.xi = t.x0 + (lane & 7);
     t.row = t.y0 + (lane >> 3);
     t.valid = t.xi < a.is && t.row < a.is;
-    t.xp = pixel_coord(t.xi, a.is);
-    t.yp = pixel_coord(a.is - 1 - t.row, a.is);   // yi = is - 1 - row, kernel.cu:716
+    t.xp = pixel_coord(t.xi, a.is, a.r_is);
+    t.yp = pixel_coord(a.is - 1 - t.row, a.is, a.r_is);   // yi = is - 1 - row, kernel.cu:716
     t.pix = (long)t.row * a.is + t.xi;
 }
 
@@ -705,7 +793,7 @@ __device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp,
         float dis = q.dx * q.dx + q.dy * q.dy;                                      // :768
         if (q.sign < 0 && dis >= a.thr) return false;                               // :769
         const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
-        if (!squared) dis = sqrtf(dis);                                             // :770-772
+        if (!squared) dis = sqrt_rn(dis);                                           // :770-772 (== sqrtf, see sqrt_rn)
         q.dis = dis;
         if constexpr (DIST >= 0)       q.frag = Dist<(DIST >= 0 ? DIST : 0)>::cdf(q.sign, dis, dp);
         else if constexpr (DIST == -2) q.frag = cdf_light_rt(dist, q.sign, dis, dp);
@@ -724,7 +812,7 @@ __device__ __forceinline__ float clip_and_depth(const Pair& q, const float* r, f
     s = ((double)s > 1e-5) ? s : (float)1e-5;              // max(sum, 1e-5) with a double literal, stored as float
     const double rs = rcp_for_div_by((double)s);           // three float quotients by one float divisor (s >= 1e-5)
     wc[0] = div_by(wc[0], rs); wc[1] = div_by(wc[1], rs); wc[2] = div_by(wc[2], rs);
-    return 1.f / (div_by(wc[0], rec_double(r, kRecRZ + 0)) + div_by(wc[1], rec_double(r, kRecRZ + 2)) + div_by(wc[2], rec_double(r, kRecRZ + 4)));   // "1. /": one rounding
+    return rcp_rn(div_by(wc[0], rec_double(r, kRecRZ + 0)) + div_by(wc[1], rec_double(r, kRecRZ + 2)) + div_by(wc[2], rec_double(r, kRecRZ + 4)));   // "1. /": one rounding
 }
 
 // surface texel index for clipped barycentrics (kernel.cu:179-185); may be >= T (reference quirk)
@@ -805,16 +893,9 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 //                      pairs from LDS and issues one hardware fp32 atomic per (tile batch, face, component).
 // Everything is wavefront-local: no barriers.
 // ---------------------------------------------------------------------------------------------
-// Backward: a pair in the batch list is one int, (face slot in the batch << 8) | pixel lane; its barycentrics are
-// computed in phase B from the gathered record (the same expressions on the same operands as everywhere else).
-// Forward: its phase B has no registers to spare for that, so the barycentrics travel with the pair, as does the
-// pixel centre.
-struct PairRecXY {         // 32 bytes: forward keeps the pixel centre with the pair (its LDS budget allows it,
-    float w0, w1, w2;      // and recomputing it costs the forward kernel an occupancy step in registers)
-    int   code;
-    float xp, yp;
-    int   pad0, pad1;
-};
+// A pair in the batch list is one int, (face slot in the batch << 8) | pixel lane; its barycentrics are computed in
+// phase B from the gathered record and the pixel centre from the lane (the same expressions on the same operands as
+// everywhere else).
 struct FaceEnt {           // 16 bytes
     int fn;                // face index inside the batch item
     int base;              // index of the face's first pair in the batch
@@ -883,14 +964,15 @@ __device__ __forceinline__ void for_each_listed_face(const RenderArgs& a, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// phase A: which pixels of the tile does each listed face reach?
+// coverage: which pixels of the tile does each listed face reach?  (once per forward call, shared by both passes)
 // ---------------------------------------------------------------------------------------------
-// The tile's mask row is first unpacked into an ascending face list in LDS.  Then eight faces are examined per
-// step: lane = (face slot, pixel row), the lane gathers its face's first record stage with vector loads -- eight
-// records in flight per step instead of one scalar-load round trip per face, which is what bounded this phase --
-// and walks the eight pixels of its row through the exact box / edge tests (same functions, same operands as a
-// per-pixel evaluation).  The eight row bytes of a face are OR-ed together across its lanes and handed, face by
-// face in ascending order, to body(fn, mask) with mask bit p = pixel lane p (row p >> 3, column p & 7).
+// One wavefront per listed tile (the same queue walk as the render kernels).  The tile's mask row is first unpacked
+// into an ascending face list in LDS.  Then eight faces are examined per step: lane = (face slot, pixel row), the lane
+// gathers its face's first record stage with vector loads -- eight records in flight per step instead of one
+// scalar-load round trip per face -- and walks the eight pixels of its row through the exact box / edge tests (same
+// functions, same operands as a per-pixel evaluation).  The eight row bytes of a face are OR-ed together across its
+// lanes; faces that own at least one pixel are appended, in ascending order, to the tile's slice of the entry pool
+// (eight 16-byte stores per step, contiguous).
 constexpr int kListCap = 128;      // faces unpacked per round (>= 64: one mask word must fit)
 
 __device__ __forceinline__ unsigned quad_or(unsigned v)
@@ -900,74 +982,157 @@ __device__ __forceinline__ unsigned quad_or(unsigned v)
     return v;
 }
 
-template <int REC, typename Body>
-__device__ __forceinline__ void for_each_face_mask(const RenderArgs& a, const TileCtx& t, int* flist, Body body)
+template <int REC>
+__global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
 {
+    __shared__ int s_flist[kListCap];
+    TileWalk tw;
+    walk_init(tw, a, 1);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int slot = lane >> 3, prow = lane & 7;
-    const float* recs_g = a.records + (long)t.b * a.nf * REC;
-    const unsigned long long* mrow = a.masks + (long)t.tile * a.chunks;
-    const int row_a = t.y0 + prow;
-    const bool row_ok = row_a < a.is;
-    const float yp_a = pixel_coord(a.is - 1 - row_a, a.is);
+    for (; tw.next < tw.total; tw.next += tw.stride) {
+        const int tile = __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]);
+        const int off = __builtin_amdgcn_readfirstlane(a.tile_off[tile]);
+        if (off < 0) continue;                      // no room in the pool: the render kernels test this tile themselves
+        TileCtx t;
+        tile_setup(t, a, tile);
+        const float* recs_g = a.records + (long)t.b * a.nf * REC;
+        const unsigned long long* mrow = a.masks + (long)tile * a.chunks;
+        const int row_a = t.y0 + prow;
+        const bool row_ok = row_a < a.is;
+        const float yp_a = pixel_coord(a.is - 1 - row_a, a.is, a.r_is);
+        CoverEnt* out = a.entries + off;
+        int nout = 0;
 
-    int word0 = 0, group0 = 0;                 // next 64-word group to load / base word of the loaded one
-    unsigned long long wv = 0ull, nz = 0ull;   // this lane's word of the loaded group / its non-zero words still to unpack
-    bool done = false;
-    while (!done) {
-        // ---- unpack up to kListCap faces
-        int nlist = 0;
-        for (;;) {
-            if (!nz) {
-                if (word0 >= a.chunks) { done = true; break; }
-                wv = word0 + lane < a.chunks ? mrow[word0 + lane] : 0ull;
-                nz = __ballot(wv != 0ull);
-                group0 = word0;
-                word0 += 64;
-                continue;
+        int word0 = 0, group0 = 0;                 // next 64-word group to load / base word of the loaded one
+        unsigned long long wv = 0ull, nz = 0ull;   // this lane's word of the loaded group / its non-zero words still to unpack
+        bool done = false;
+        while (!done) {
+            // ---- unpack up to kListCap faces
+            int nlist = 0;
+            for (;;) {
+                if (!nz) {
+                    if (word0 >= a.chunks) { done = true; break; }
+                    wv = word0 + lane < a.chunks ? mrow[word0 + lane] : 0ull;
+                    nz = __ballot(wv != 0ull);
+                    group0 = word0;
+                    word0 += 64;
+                    continue;
+                }
+                const int j = __builtin_ctzll(nz);
+                const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), j) << 32)
+                                           | (unsigned)__builtin_amdgcn_readlane((int)wv, j);
+                const int cnt = __popcll(w);
+                if (nlist + cnt > kListCap) break;                       // the word stays in nz for the next round
+                nz &= nz - 1;
+                if ((w >> lane) & 1ull) s_flist[nlist + __popcll(w & lt)] = (group0 + j) * 64 + lane;
+                nlist += cnt;
             }
-            const int j = __builtin_ctzll(nz);
-            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), j) << 32)
-                                       | (unsigned)__builtin_amdgcn_readlane((int)wv, j);
-            const int cnt = __popcll(w);
-            if (nlist + cnt > kListCap) break;                       // the word stays in nz for the next round
-            nz &= nz - 1;
-            if ((w >> lane) & 1ull) flist[nlist + __popcll(w & lt)] = (group0 + j) * 64 + lane;
-            nlist += cnt;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- eight faces per step
-        for (int i0 = 0; i0 < nlist; i0 += 8) {
-            const bool has = i0 + slot < nlist;
-            const int fn = flist[has ? i0 + slot : i0];
-            float r[kRecStage1];
-            gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
-            unsigned m8 = 0u;
-            if (has && row_ok) {
+            __builtin_amdgcn_wave_barrier();
+            // ---- eight faces per step
+            for (int i0 = 0; i0 < nlist; i0 += 8) {
+                const bool has = i0 + slot < nlist;
+                const int fn = s_flist[has ? i0 + slot : i0];
+                float r[kRecStage1];
+                gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
+                unsigned m8 = 0u;
+                if (has && row_ok) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const float xp = pixel_coord(t.x0 + c, a.is);
-                    bool live = t.x0 + c < a.is && inside_box(r, xp, yp_a);
-                    if (live) {
-                        Pair q;
-                        barycentrics(q, r, xp, yp_a);
-                        live = !beyond_an_edge(q, r);
+                    for (int c = 0; c < 8; c++) {
+                        const float xp = pixel_coord(t.x0 + c, a.is, a.r_is);
+                        bool live = t.x0 + c < a.is && inside_box(r, xp, yp_a);
+                        if (live) {
+                            Pair q;
+                            barycentrics(q, r, xp, yp_a);
+                            live = !beyond_an_edge(q, r);
+                        }
+                        m8 |= (live ? 1u : 0u) << c;
                     }
-                    m8 |= (live ? 1u : 0u) << c;
+                }
+                const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
+                const unsigned hi = (unsigned)__shfl_down((int)v, 4);                  // lane 8s reads lane 8s+4 (rows 4-7)
+                const bool owns = prow == 0 && (v | hi) != 0u;
+                const unsigned long long keep = __ballot(owns);
+                if (owns) {
+                    CoverEnt e;
+                    e.fn = fn; e.npix = __popc(v) + __popc(hi); e.lo = v; e.hi = hi;
+                    out[nout + __popcll(keep & lt)] = e;
+                }
+                nout += __popcll(keep);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) a.tile_cnt[tile] = nout;
+    }
+}
+
+// Walks a tile's coverage entries in ascending face order and calls body(fn, mask, false) for each, then
+// body(0, 0, true) once (the caller flushes its open batch there) -- from ONE call site, so that the caller's phase B
+// is compiled once.  64 entries arrive by one coalesced 16-byte load per lane; v_readlane hands them to the
+// (wave-uniform) body one by one.
+// A tile without a slice of the entry pool (tile_off < 0) produces its entries here instead, up to 64 at a time: its
+// mask row is walked with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact
+// per-pixel tests (collect_pairs) -- same entries, only slower.
+template <int REC, typename Body>
+__device__ __forceinline__ void for_each_entry(const RenderArgs& a, const TileCtx& t, Body body)
+{
+    const int lane = threadIdx.x & 63;
+    const int off = __builtin_amdgcn_readfirstlane(a.tile_off[t.tile]);
+    const int cnt = off >= 0 ? __builtin_amdgcn_readfirstlane(a.tile_cnt[t.tile]) : 0;
+    const int4* ents = reinterpret_cast<const int4*>(a.entries + max(off, 0));
+    // state of the mask-row walk of the fallback
+    const unsigned long long* mrow = a.masks + (long)t.tile * a.chunks;
+    const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
+    int word0 = 0, group0 = 0, wbase = 0;
+    unsigned long long wv = 0ull, nz = 0ull, w = 0ull;
+    bool exhausted = off >= 0;
+
+    int e0 = 0, n = 0, j = 0;
+    int4 e = make_int4(0, 0, 0, 0);
+    for (;;) {
+        if (j == n) {
+            // ---- next chunk of up to 64 entries into lane-indexed registers
+            j = 0; n = 0;
+            if (off >= 0) {
+                n = min(64, cnt - e0);
+                if (lane < n) e = ents[e0 + lane];
+                e0 += n;
+            } else {
+                while (n < 64 && !exhausted) {
+                    if (!w) {
+                        if (!nz) {
+                            if (word0 >= a.chunks) { exhausted = true; break; }
+                            wv = word0 + lane < a.chunks ? mrow[word0 + lane] : 0ull;
+                            nz = __ballot(wv != 0ull);
+                            group0 = word0;
+                            word0 += 64;
+                            continue;
+                        }
+                        const int jj = __builtin_ctzll(nz);
+                        nz &= nz - 1;
+                        w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), jj) << 32)
+                          | (unsigned)__builtin_amdgcn_readlane((int)wv, jj);
+                        wbase = (group0 + jj) * 64;
+                        continue;
+                    }
+                    const int fn = wbase + __builtin_ctzll(w);
+                    w &= w - 1;
+                    Pair q;
+                    const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
+                    if (m) {
+                        if (lane == n) e = make_int4(fn, 0, (int)(unsigned)m, (int)(unsigned)(m >> 32));
+                        n++;
+                    }
                 }
             }
-            const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
-            const int nslots = min(8, nlist - i0);
-            for (int sl = 0; sl < nslots; sl++) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, 8 * sl);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)v, 8 * sl + 4);
-                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-                if (!m) continue;
-                body(__builtin_amdgcn_readlane(fn, 8 * sl), m);
-            }
+            if (n <= 0) { body(0, 0ull, true); return; }
         }
-        __builtin_amdgcn_wave_barrier();
+        const int fn = __builtin_amdgcn_readlane(e.x, j);
+        const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32)
+                                   | (unsigned)__builtin_amdgcn_readlane(e.z, j);
+        j++;
+        body(fn, m, false);
     }
 }
 
@@ -988,7 +1153,8 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int WAVES = kThreads / 64;
-    __shared__ __attribute__((aligned(16))) PairRecXY s_pair[WAVES][64];
+    __shared__ int s_pair[WAVES][64];
+    __shared__ float2 s_xy[WAVES][64];                      // pixel centres of the tile, fetched by pair lanes
     __shared__ __attribute__((aligned(16))) FwdRes  s_res[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
 
@@ -1000,11 +1166,43 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 
     TileWalk tw;
     walk_init(tw, a, WAVES);
+
+    // Tiles no face is listed for: what the loop below leaves for an untouched pixel (kernel.cu:728-740, :845-861).
+    // First, so that these stores (two thirds of the output planes in the headline scene) drain while the wave computes.
+#if GENDR_ABLATE != 5
+    for (int r = tw.rank; r < tw.empties; r += tw.stride) {
+        TileCtx t;
+        tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]));
+        if (!t.valid) continue;
+        float* out = a.rgba + (long)t.b * 4 * P + t.pix;
+        float* aux = a.aux + (long)t.b * 2 * P + t.pix;
+        out[3 * P] = 0.f;
+        if (!rgb_soft) {
+            if (!a.p.background_from_buffer) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) out[k * P] = a.p.background[k];
+            }
+            aux[0] = 10000000.f;
+            aux[P] = -1.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float bgk = a.p.background_from_buffer ? out[k * P] : a.p.background[k];
+                out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0;
+            }
+            aux[0] = a.softmax_sum0;
+            aux[P] = a.p.aggr_rgb_eps;
+        }
+    }
+#endif
+
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     TileCtx t;
     tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]));
+
+    s_xy[wave][lane] = make_float2(t.xp, t.yp);
 
     // per-pixel state, kernel.cu:728-740
     float bg[3];
@@ -1030,16 +1228,17 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 #endif
         // ---- phase B: one pair per lane
         if (lane < npairs) {
-            const PairRecXY pr = s_pair[wave][lane];
-            const int fn = s_face[wave][pr.code >> 8].fn;
+            const int code = s_pair[wave][lane];
+            const int fn = s_face[wave][code >> 8].fn;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
             const float* rg = recs_g + (long)fn * REC;
-            r[kRecBits] = rg[kRecBits];
+            gather_record<kGatherW0, kGatherW1>(r, rg);
             gather_record<kGatherA0, kGatherA1>(r, rg);
+            const float2 pc = s_xy[wave][code & 63];
+            const float pxp = pc.x, pyp = pc.y;
             Pair q;
-            q.w0 = pr.w0; q.w1 = pr.w1; q.w2 = pr.w2;
-            const float pxp = pr.xp, pyp = pr.yp;
+            barycentrics(q, r, pxp, pyp);
             FwdRes res;
             res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fn = fn; res.pad1 = 0;
             if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) {
@@ -1109,17 +1308,11 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         my_pairs = 0ull;
     };
 
-    for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
-        Pair q;
-        unsigned long long m = collect_pairs<REC>(t, rp, q);
-        if (!m) return;
+    for_each_entry<REC>(a, t, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
         auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
             if ((mm >> lane) & 1ull) {
-                PairRecXY pr;
-                pr.w0 = q.w0; pr.w1 = q.w1; pr.w2 = q.w2;
-                pr.code = (nfaces << 8) | lane; pr.xp = t.xp; pr.yp = t.yp; pr.pad0 = 0; pr.pad1 = 0;
                 const int at = npairs + __popcll(mm & lt);
-                s_pair[wave][at] = pr;
+                s_pair[wave][at] = (nfaces << 8) | lane;
                 my_pairs |= 1ull << at;
             }
             if (lane == 0) {
@@ -1130,20 +1323,19 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             npairs += __popcll(mm);
             nfaces += 1;
         };
-        if (npairs + __popcll(m) > 64) {
+        if (flush ? npairs > 0 : npairs + __popcll(m) > 64) {
             // top the batch up with the first pairs of this face (its pixels stay in ascending-face order: the rest
             // of the face opens the next batch), unless the room left is not worth a second list entry
             const int room = 64 - npairs;
-            if (room >= kSplitMin) {
+            if (!flush && room >= kSplitMin) {
                 const unsigned long long m1 = __ballot(((m >> lane) & 1ull) && __popcll(m & lt) < room);
                 emit(m1);
                 m &= ~m1;
             }
             run_batch();
         }
-        emit(m);
+        if (!flush) emit(m);
     });
-    if (npairs > 0) run_batch();
 
     if (t.valid) {
         // epilogue, kernel.cu:845-861
@@ -1165,31 +1357,6 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     __builtin_amdgcn_wave_barrier();
     }   // tile loop
 
-    // Tiles no face is listed for: what the loop above leaves for an untouched pixel (kernel.cu:728-740, :845-861).
-    for (int r = tw.rank; r < tw.empties; r += tw.stride) {
-        TileCtx t;
-        tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]));
-        if (!t.valid) continue;
-        float* out = a.rgba + (long)t.b * 4 * P + t.pix;
-        float* aux = a.aux + (long)t.b * 2 * P + t.pix;
-        out[3 * P] = 0.f;
-        if (!rgb_soft) {
-            if (!a.p.background_from_buffer) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) out[k * P] = a.p.background[k];
-            }
-            aux[0] = 10000000.f;
-            aux[P] = -1.f;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float bgk = a.p.background_from_buffer ? out[k * P] : a.p.background[k];
-                out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0;
-            }
-            aux[0] = a.softmax_sum0;
-            aux[P] = a.p.aggr_rgb_eps;
-        }
-    }
 }
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
@@ -1228,14 +1395,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_
 // ---------------------------------------------------------------------------------------------
 template <int TEXM> struct GradSlots { static constexpr int n = TEXM == kTexSurface1 ? 12 : (TEXM == kTexVertex ? 18 : 9); };
 
-struct PixIn {             // 40 bytes: per-pixel inputs of the backward pass, kernel.cu:916-917, :973, :980, :1013, :1021
-    float g[4], out[4], ssum, smax;
+struct PixIn {             // 48 bytes: per-pixel inputs of the backward pass, kernel.cu:916-917, :973, :980, :1013, :1021
+    float g[4], out[4], ssum, smax, xp, yp;
 };
 
-// WIDE selects phase A: 1 = eight faces per step (for_each_face_mask), 0 = one face per step with scalar-loaded records
-// (for_each_listed_face).  The wide walk wins when tiles list many faces (small faces relative to a tile: the
-// headline scene lists 17 per tile on average); with one to three faces per tile -- large images -- it mostly idles.
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 {
     constexpr int REC = record_floats(TEXM);
@@ -1243,7 +1407,6 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     constexpr int NT = NG > 9 ? NG - 9 : 1;
     constexpr int WAVES = kThreads / 64;
     __shared__ int s_pair[WAVES][64];
-    __shared__ int s_flist[WAVES][WIDE ? kListCap : 1];
     __shared__ __attribute__((aligned(16))) PixIn   s_pix[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
     __shared__ float s_val[WAVES][NG * 65];      // per-pair gradient partials, component-major, rows padded to 65
@@ -1267,7 +1430,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         PixIn pi;
 #pragma unroll
         for (int k = 0; k < 4; k++) { pi.g[k] = 0.f; pi.out[k] = 0.f; }
-        pi.ssum = 1.f; pi.smax = 0.f;
+        pi.ssum = 1.f; pi.smax = 0.f; pi.xp = t.xp; pi.yp = t.yp;
         if (t.valid) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1298,8 +1461,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             const float* rg = recs_g + (long)fn * REC;
             gather_record<kGatherW0, kGatherW1>(r, rg);
             gather_record<kGatherA0, kGatherA1>(r, rg);
-            float pxp, pyp;
-            pair_pixel(pxp, pyp, t, code & 63, a.is);
+            const float pxp = px.xp, pyp = px.yp;
             Pair q;
             barycentrics(q, r, pxp, pyp);
 
@@ -1316,7 +1478,9 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                 float C_xy = 0.f;
                 float C_alpha = px.g[3];
                 if (alpha_func != kAlphaHard) {
-                    if constexpr (ALPHA > 0)        C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    if constexpr ((ALPHA == kProbabilistic || ALPHA == kEinstein) && !GENDR_EXACT_GRADIENT)
+                                                    C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad_fp32(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+                    else if constexpr (ALPHA > 0)   C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
                     else if constexpr (ALPHA == -2) C_alpha *= tconorm_grad_light_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
                     else                            C_alpha *= tconorm_grad_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
                 }
@@ -1351,7 +1515,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                         }
                     } else if (front || a.p.double_side) {                      // :1006-1030
                         const float zn = div_by(a.p.far_ - zp, a.r_zrange);
-                        const float zs = q.frag * expf(div_by(zn - px.smax, a.r_gamma)) / px.ssum;   // :1010
+                        const float zs = grad_div(q.frag * expf(div_by(zn - px.smax, a.r_gamma)), px.ssum);   // :1010
                         float cc[3]; int own;
                         sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
                         float C_rgb = 0.f;
@@ -1368,11 +1532,20 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                             C_rgb += px.g[k] * (cc[k] - px.out[k]);             // :1021
                         }
                         C_rgb *= zs;                                            // :1023
-                        C_xy += C_rgb / q.frag;                                 // :1024
+                        C_xy += grad_div(C_rgb, q.frag);                        // :1024
+#if GENDR_EXACT_GRADIENT
                         const float C_z = div_by(div_by(C_rgb, a.r_gamma), a.r_nzrange) * zp * zp;   // :1026
                         gv[2] = div_by(div_by(C_z * wc[0], rec_double(r, kRecRZ + 0)), rec_double(r, kRecRZ + 0));
                         gv[5] = div_by(div_by(C_z * wc[1], rec_double(r, kRecRZ + 2)), rec_double(r, kRecRZ + 2));
                         gv[8] = div_by(div_by(C_z * wc[2], rec_double(r, kRecRZ + 4)), rec_double(r, kRecRZ + 4));
+#else
+                        // C_rgb / gamma / (near - far) * zp^2 * w_k / z_k^2 with the float reciprocals (:1026-1029)
+                        const float C_z = C_rgb * ((float)a.r_gamma * (float)a.r_nzrange) * zp * zp;
+                        const float rz0 = (float)rec_double(r, kRecRZ + 0), rz1 = (float)rec_double(r, kRecRZ + 2), rz2 = (float)rec_double(r, kRecRZ + 4);
+                        gv[2] = C_z * wc[0] * (rz0 * rz0);
+                        gv[5] = C_z * wc[1] * (rz1 * rz1);
+                        gv[8] = C_z * wc[2] * (rz2 * rz2);
+#endif
                     }
 
                     // distance gradient, kernel.cu:1034-1052.  Heaviside: D' = 0 times uninitialised
@@ -1393,6 +1566,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                             // the float square root, one double reciprocal serves all six quotients exactly (div_by);
                             // below 1e-6 the divisor is the double literal and the true divisions are kept.
                             const float len = q.dis;   // == sqrtf(dx*dx + dy*dy): the very value soft_fragment() computed (:771)
+#if GENDR_EXACT_GRADIENT
                             if ((double)len >= 1e-6) {
                                 const double rlen = rcp_for_div_by((double)len);
 #pragma unroll
@@ -1407,6 +1581,15 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                                     gv[3 * k + 1] = (float)((double)(q.sign * C_xy * tw[k] * q.dy) / 1e-6);
                                 }
                             }
+#else
+                            const float rlen = ((double)len >= 1e-6) ? grad_rcp(len) : 1e6f;
+                            const float sx = q.sign * C_xy * (q.dx * rlen), sy = q.sign * C_xy * (q.dy * rlen);
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                gv[3 * k + 0] = sx * tw[k];
+                                gv[3 * k + 1] = sy * tw[k];
+                            }
+#endif
                         }
                     }
                 }
@@ -1445,7 +1628,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         nfaces = 0;
     };
 
-    auto take_face = [&](int fn, unsigned long long m) __attribute__((always_inline)) {
+    for_each_entry<REC>(a, t, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
         auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
             if ((mm >> lane) & 1ull) s_pair[wave][npairs + __popcll(mm & lt)] = (nfaces << 8) | lane;
             if (lane == 0) {
@@ -1456,59 +1639,72 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             npairs += __popcll(mm);
             nfaces += 1;
         };
-        if (npairs + __popcll(m) > 64) {
+        if (flush ? npairs > 0 : npairs + __popcll(m) > 64) {
             const int room = 64 - npairs;                       // top the batch up, see render_forward_body
-            if (room >= kSplitMin) {
+            if (!flush && room >= kSplitMin) {
                 const unsigned long long m1 = __ballot(((m >> lane) & 1ull) && __popcll(m & lt) < room);
                 emit(m1);
                 m &= ~m1;
             }
             run_batch();
         }
-        emit(m);
-    };
-    if constexpr (WIDE) {
-        for_each_face_mask<REC>(a, t, s_flist[wave], take_face);
-    } else {
-        for_each_listed_face<REC>(a, t, [&](int fn, RecPtr rp) __attribute__((always_inline)) {
-            Pair q;
-            const unsigned long long m = collect_pairs<REC>(t, rp, q);
-            if (m) take_face(fn, m);
-        });
-    }
-    if (npairs > 0) run_batch();
+        if (!flush) emit(m);
+    });
     __builtin_amdgcn_wave_barrier();
     }   // tile loop
 }
 
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) void render_backward_kernel(const RenderArgs a)
 {
-    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
 
 // register budget capped for 5 waves per SIMD (96 VGPRs), see render_forward_kernel_w6
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BWD_WAVES))) void render_backward_kernel_w5(const RenderArgs a)
 {
-    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
 
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_LIGHT_BWD_WAVES))) void render_backward_kernel_wl(const RenderArgs a)
 {
-    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
 
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_FULL_WAVES))) void render_backward_kernel_wf(const RenderArgs a)
 {
-    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
 }
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int WIDE>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_HALPHA_WAVES))) void render_backward_kernel_wa(const RenderArgs a)
 {
-    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM, WIDE>(a);
+    render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+
+// Exhaustive check of sqrt_rn / rcp_rn against the compiler's correctly rounded expansions: every float bit pattern
+// in [2^-96, 2^96] (what == 0: sqrt, 1: reciprocal of +x, 2: reciprocal of -x).  out[0] = mismatches, out[1] = tested,
+// out[2..] = up to 14 offending bit patterns.
+__global__ __launch_bounds__(256) void selftest_kernel(int what, unsigned long long* out)
+{
+    const unsigned lo = __float_as_uint(0x1p-96f), hi = __float_as_uint(0x1p+96f);
+    unsigned long long bad = 0, n = 0;
+    for (unsigned long long u = (unsigned long long)lo + blockIdx.x * 256ull + threadIdx.x; u <= hi; u += (unsigned long long)gridDim.x * 256ull) {
+        float x = __uint_as_float((unsigned)u);
+        if (what == 2) x = -x;
+        const float got = what == 0 ? sqrt_rn(x) : rcp_rn(x);
+        const float want = what == 0 ? sqrtf(x) : 1.f / x;
+        n++;
+        if (__float_as_uint(got) != __float_as_uint(want)) {
+            bad++;
+            const unsigned long long slot = atomicAdd(out + 15, 1ull);
+            if (slot < 13) out[2 + slot] = u;
+        }
+    }
+    atomicAdd(out + 0, bad);
+    atomicAdd(out + 1, n);
 }
 
 }  // namespace gendr

@@ -70,6 +70,73 @@ GENDR_HD double rcp_for_div_by(double b)
 #endif
 }
 
+// ---- correctly rounded square root and reciprocal, short forms ----------------------------------------------------
+// hipcc's expansions of sqrtf() and of 1.f / x are correctly rounded for EVERY input (denormals, huge values) and pay
+// for it: 54 and 43 issue cycles per wave on MI355X (tools/micro/opbench.hip).  The pair math only ever sees
+// arguments in the normal range, where the classic fused-multiply-add refinements of the hardware estimates
+// (v_rsq_f32 / v_rcp_f32, 1 ulp) are enough: 8 and 5 instructions.  Their results equal sqrtf(x) and 1.f / x for
+// every float in [2^-96, 2^96] -- verified EXHAUSTIVELY, all 1.6e9 bit patterns, by gendr_selftest() on the GPU
+// (tests/test_gpu_exact_math.py); outside that range, and for 0 / inf / NaN, the compiler's expansion is used.
+GENDR_HD float sqrt_rn(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!(x >= 0x1p-96f && x <= 0x1p+96f)) return sqrtf(x);
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y;                                         // ~ sqrt(x)
+    float h = 0.5f * y;                                      // ~ 1 / (2 sqrt(x))
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g, g, x);                // exact residual of a faithful g
+    return __builtin_fmaf(d, h, g);
+#else
+    return sqrtf(x);
+#endif
+}
+GENDR_HD float rcp_rn(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!(fabsf(x) >= 0x1p-96f && fabsf(x) <= 0x1p+96f)) return 1.f / x;
+    float y = __builtin_amdgcn_rcpf(x);
+    y = __builtin_fmaf(__builtin_fmaf(-x, y, 1.f), y, y);
+    return __builtin_fmaf(__builtin_fmaf(-x, y, 1.f), y, y);
+#else
+    return 1.f / x;
+#endif
+}
+
+// ---- gradient-side arithmetic (backward kernel only) ----------------------------------------------------------
+// The partials of a (pixel, face) pair are summed per face in an order that already differs from the reference's
+// (and from run to run: float atomics), so a gradient can only be compared within a tolerance.  What feeds ONLY
+// those sums is therefore computed to fp32 accuracy (<= 1 ulp per quotient) instead of with the reference's exact
+// rounding: v_rcp_f32 plus one correction step instead of the IEEE division expansion (measured on MI355X: 15 vs 43
+// issue cycles per wave; an exact double-reciprocal quotient costs 13 + 41 for its reciprocal).  Everything the
+// backward pass RECOMPUTES from the forward pass -- barycentrics, distance, CDF, depth: whatever decides which pairs
+// contribute -- keeps the forward kernel's exact arithmetic.  -DGENDR_EXACT_GRADIENT=1 restores the reference's
+// rounding everywhere (diagnostic).
+#ifndef GENDR_EXACT_GRADIENT
+#define GENDR_EXACT_GRADIENT 0
+#endif
+GENDR_HD float grad_rcp(float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
+    float y = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, y, 1.f), y, y);
+#else
+    return 1.f / b;
+#endif
+}
+GENDR_HD float grad_div(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
+    const float y = __builtin_amdgcn_rcpf(b);
+    const float q = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-q, b, a), y, q);
+#else
+    return a / b;
+#endif
+}
+
 GENDR_HD float quiet_nan() { return __builtin_nanf(""); }
 
 // normal CDF of a float argument (kernel.cu:293 calls CUDA's normcdf(float)).
@@ -342,12 +409,14 @@ template <> struct TConorm<kProbabilistic> {
     static GENDR_HD float grad(float A, float b, float) {                                                // :577-578
         return (float)((1. - (double)A) / fmax(1. - (double)b, 1e-6));
     }
+    static GENDR_HD float grad_fp32(float A, float b, float) { return grad_div(1.f - A, fmaxf(1.f - b, 1e-6f)); }
 };
 template <> struct TConorm<kEinstein> {
     static GENDR_HD float fold(float a, float b, float) { return (a + b) / (1 + a * b); }                // :487-488
     static GENDR_HD float grad(float A, float b, float) {                                                // :580-581
         return (float)((1. - (double)(A * A)) / fmax(1. - (double)(b * b), 1e-6));
     }
+    static GENDR_HD float grad_fp32(float A, float b, float) { return grad_div(1.f - A * A, fmaxf(1.f - b * b, 1e-6f)); }
 };
 template <> struct TConorm<kHamacher> {
     static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :490-498

@@ -179,6 +179,12 @@ int gendr_project_faces_backward(const float* vertices, const int* face_index, c
                                  const float* grad_face_vertices, float* grad_vertices, float* grad_camera,
                                  int B, int nv, int nf, int index_batched, int perspective, float width_or_scale, void* stream);
 
+/* Self-test of the short correctly-rounded forms the pair math uses for sqrtf(x) and 1.f / x (gendr_math.h: sqrt_rn,
+ * rcp_rn): compares them with the compiler's IEEE expansions for EVERY float bit pattern in [2^-96, 2^96].
+ *   what: 0 sqrt, 1 reciprocal of +x, 2 reciprocal of -x.   report16 (device, 16 x u64): [0] mismatches, [1] values
+ *   tested, [2..14] offending bit patterns. */
+int gendr_selftest(int what, unsigned long long* report16, void* stream);
+
 const char* gendr_error_string(int code);
 int gendr_abi_version(void);
 int gendr_params_size(void);   /* sizeof(gendr_params) as compiled, for binding sanity checks */

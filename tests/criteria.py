@@ -51,7 +51,8 @@ def check(res, noise, keys=('rgba', 'aggrs', 'grad_faces_cond', 'grad_textures_c
             bad.append('%s: p99 %.2e vs fp32-noise p99 %.2e' % (k, e['p99_rel'], n['p99_rel']))
         if k not in RAW_GRAD_KEYS and e['max_rel'] > max(TOL, 2 * n['max_rel']):
             bad.append('%s: max %.2e vs fp32-noise max %.2e' % (k, e['max_rel'], n['max_rel']))
-        if e['frac_gt_1e5'] > max(1e-3, 2 * n['frac_gt_1e5']):
+        # raw gradients: p99 <= 1e-5 already allows 1 % of the elements above it (summation order of cancelling sums)
+        if e['frac_gt_1e5'] > max(1e-2 if k in RAW_GRAD_KEYS else 1e-3, 2 * n['frac_gt_1e5']):
             bad.append('%s: fraction>1e-5 %.2e vs fp32-noise %.2e' % (k, e['frac_gt_1e5'], n['frac_gt_1e5']))
     return bad
 

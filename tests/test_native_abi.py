@@ -77,11 +77,17 @@ def test_validate_shapes(native_lib):
 
 def test_workspace_bytes(native_lib):
     p = _params(image_size=256)
-    # boxes 16 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile lists 4 B per tile,
-    # control block (queue lengths); every part 256-byte aligned
+    # bin record 64 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile queue + entry offset +
+    # entry count 4 B each per tile, the entry pool (16 B per slot: 32 per tile + 64 per face, at most tiles * faces),
+    # control block (24 counters, 4 KiB apart); every part 256-byte aligned
     n = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(p))
-    control = 16 * 1024 * 4                  # 16 counters, 4 KiB apart
-    assert n == 2 * 1280 * 16 + 2 * 1280 * 224 + 2 * 32 * 32 * 20 * 8 + 2 * 32 * 32 * 4 + control
+    control = 24 * 1024 * 4
+    tiles = 2 * 32 * 32
+    pool = (32 * tiles + 64 * 2 * 1280) * 16
+    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + 3 * tiles * 4 + pool + control
+    # tiny problems: the pool never exceeds one slot per (tile, face)
+    small = native_lib.gendr_workspace_bytes(1, 2, 1, ctypes.byref(_params(image_size=8)))
+    assert small == 256 * 5 + 512 + 256 + control    # five sub-256-byte parts, 2 records (448 B), an 8-slot pool, the counters
     assert native_lib.gendr_workspace_bytes(2, 1280, 3, ctypes.byref(_params(image_size=256, texture_type='vertex'))) > n
     assert native_lib.gendr_workspace_bytes(2, 1280, 0, ctypes.byref(p)) == 0
 
