@@ -52,7 +52,7 @@
 #define GENDR_LIGHT_BWD_WAVES 4
 #endif
 #ifndef GENDR_BWD_WAVES
-#define GENDR_BWD_WAVES 5
+#define GENDR_BWD_WAVES 4
 #endif
 
 #ifndef GENDR_BIN_LOOP_MAX
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
 
 // Walks a tile's coverage entries in ascending face order and calls body(fn, mask, false) for each, then
 // body(0, 0, true) once (the caller flushes its open batch there) -- from ONE call site, so that the caller's phase B
-// is compiled once.  64 entries arrive by one coalesced 16-byte load per lane; v_readlane hands them to the
+// is compiled once (two sites doubled the kernels' code).  64 entries arrive by one coalesced 16-byte load per lane; v_readlane hands them to the
 // (wave-uniform) body one by one.
 // A tile without a slice of the entry pool (tile_off < 0) produces its entries here instead, up to 64 at a time: its
 // mask row is walked with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact
@@ -1126,13 +1126,15 @@ __device__ __forceinline__ void for_each_entry(const RenderArgs& a, const TileCt
                     }
                 }
             }
-            if (n <= 0) { body(0, 0ull, true); return; }
         }
-        const int fn = __builtin_amdgcn_readlane(e.x, j);
-        const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32)
-                                   | (unsigned)__builtin_amdgcn_readlane(e.z, j);
+        // one call site: the flush is an entry like any other
+        const bool flush = n <= 0;
+        const int fn = flush ? 0 : __builtin_amdgcn_readlane(e.x, j);
+        const unsigned long long m = flush ? 0ull
+            : (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j));
         j++;
-        body(fn, m, false);
+        body(fn, m, flush);
+        if (flush) return;
     }
 }
 
