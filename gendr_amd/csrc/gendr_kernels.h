@@ -86,6 +86,7 @@ typedef float f8v  __attribute__((ext_vector_type(8), aligned(4)));
 typedef float f4v  __attribute__((ext_vector_type(4), aligned(4)));
 
 typedef float f2v  __attribute__((ext_vector_type(2), aligned(4)));
+typedef int   i4v  __attribute__((ext_vector_type(4)));
 
 // Floats [BEGIN, END) of a face record -> dst[BEGIN..END) with the widest scalar loads that fit
 // (s_load_dwordx16 / x8 / x4 / x2): one wait per stage instead of one per field.
@@ -194,7 +195,8 @@ struct RenderArgs {
     CoverEnt*     entries;      // entry pool: 8 regions of ent_cap8 entries (one per tile queue)
     int*          tile_off;     // [B * tiles_per_image]: first entry of the tile, or -1 (pool exhausted: the render
                                 //   kernels then run the per-pixel tests themselves, from the mask row)
-    int*          tile_cnt;     // [B * tiles_per_image]: number of entries (faces that own a pixel of the tile)
+    int4*         tile_info;    // [B * tiles_per_image], parallel to tile_list: (tile, first entry or -1, entries, 0) of the
+                                //   queue slot, written by cover_kernel: one scalar load tells a render wave all it needs
     long          ent_cap8;     // capacity of one region of the entry pool
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
@@ -994,7 +996,10 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
     for (; tw.next < tw.total; tw.next += tw.stride) {
         const int tile = __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]);
         const int off = __builtin_amdgcn_readfirstlane(a.tile_off[tile]);
-        if (off < 0) continue;                      // no room in the pool: the render kernels test this tile themselves
+        if (off < 0) {                              // no room in the pool: the render kernels test this tile themselves
+            if (lane == 0) a.tile_info[tw.qbase + tw.next] = make_int4(tile, -1, 0, 0);
+            continue;
+        }
         TileCtx t;
         tile_setup(t, a, tile);
         const float* recs_g = a.records + (long)t.b * a.nf * REC;
@@ -1063,7 +1068,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) a.tile_cnt[tile] = nout;
+        if (lane == 0) a.tile_info[tw.qbase + tw.next] = make_int4(tile, off, nout, 0);
     }
 }
 
@@ -1075,11 +1080,9 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
 // mask row is walked with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact
 // per-pixel tests (collect_pairs) -- same entries, only slower.
 template <int REC, typename Body>
-__device__ __forceinline__ void for_each_entry(const RenderArgs& a, const TileCtx& t, Body body)
+__device__ __forceinline__ void for_each_entry(const RenderArgs& a, const TileCtx& t, int off, int cnt, Body body)
 {
     const int lane = threadIdx.x & 63;
-    const int off = __builtin_amdgcn_readfirstlane(a.tile_off[t.tile]);
-    const int cnt = off >= 0 ? __builtin_amdgcn_readfirstlane(a.tile_cnt[t.tile]) : 0;
     const int4* ents = reinterpret_cast<const int4*>(a.entries + max(off, 0));
     // state of the mask-row walk of the fallback
     const unsigned long long* mrow = a.masks + (long)t.tile * a.chunks;
@@ -1201,8 +1204,9 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries): scalar load
     TileCtx t;
-    tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]));
+    tile_setup(t, a, ti.x);
 
     s_xy[wave][lane] = make_float2(t.xp, t.yp);
 
@@ -1310,7 +1314,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         my_pairs = 0ull;
     };
 
-    for_each_entry<REC>(a, t, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
+    for_each_entry<REC>(a, t, ti.y, ti.z, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
         auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
             if ((mm >> lane) & 1ull) {
                 const int at = npairs + __popcll(mm & lt);
@@ -1426,8 +1430,9 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries): scalar load
     TileCtx t;
-    tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]));
+    tile_setup(t, a, ti.x);
     {
         PixIn pi;
 #pragma unroll
@@ -1619,7 +1624,11 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             for (; i + 4 <= cnt; i += 4) { v0 += col[i]; v1 += col[i + 1]; v2 += col[i + 2]; v3 += col[i + 3]; }
             for (; i < cnt; i++) v0 += col[i];
             const float v = (v0 + v1) + (v2 + v3);
+#if GENDR_ABLATE == 8
+            if (v == 12345.678f) {
+#else
             if (v != 0.f) {
+#endif
                 const long face_lin = (long)t.b * a.nf + fe.fn;
                 if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
                 else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
@@ -1630,7 +1639,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         nfaces = 0;
     };
 
-    for_each_entry<REC>(a, t, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
+    for_each_entry<REC>(a, t, ti.y, ti.z, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
         auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
             if ((mm >> lane) & 1ull) s_pair[wave][npairs + __popcll(mm & lt)] = (nfaces << 8) | lane;
             if (lane == 0) {

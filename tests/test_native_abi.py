@@ -84,7 +84,7 @@ def test_workspace_bytes(native_lib):
     control = 24 * 1024 * 4
     tiles = 2 * 32 * 32
     pool = (32 * tiles + 64 * 2 * 1280) * 16
-    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + 3 * tiles * 4 + pool + control
+    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + 2 * tiles * 4 + tiles * 16 + pool + control
     # tiny problems: the pool never exceeds one slot per (tile, face)
     small = native_lib.gendr_workspace_bytes(1, 2, 1, ctypes.byref(_params(image_size=8)))
     assert small == 256 * 5 + 512 + 256 + control    # five sub-256-byte parts, 2 records (448 B), an 8-slot pool, the counters
