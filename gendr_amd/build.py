@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
 SOURCES = ["gendr_capi.hip"]
-HEADERS = ["gendr_kernels.h", "gendr_math.h", "gendr_project.h", "gendr_voxel.h", "gendr_texture.h", "gendr_light.h", os.path.join("..", "..", "include", "gendr_hip.h")]
+HEADERS = ["gendr_kernels.h", "gendr_math.h", "gendr_project.h", "gendr_voxel.h", "gendr_texture.h", "gendr_light.h", "gendr_f64.h", os.path.join("..", "..", "include", "gendr_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-munsafe-fp-atomics", "-fno-slp-vectorize"]
 

@@ -13,6 +13,7 @@
 #include "gendr_voxel.h"
 #include "gendr_texture.h"
 #include "gendr_light.h"
+#include "gendr_f64.h"
 
 using namespace gendr;
 
@@ -336,6 +337,68 @@ float gendr_cull_radius(const gendr_params* p)
     last = k;
     last_r = r;
     return r;
+}
+
+// ---- float64 instantiation (kernel.cu:1102,1117,1189 AT_DISPATCH_FLOATING_TYPES) ------------------------------------
+static int fill_args_f64(f64::Args& a, const double* faces, const double* textures, void* workspace,
+                         int B, int nf, int T, const gendr_params* p)
+{
+    memset(&a, 0, sizeof(a));
+    a.faces = faces; a.textures = textures; a.info = static_cast<const double*>(workspace);
+    a.B = B; a.nf = nf; a.T = T; a.R = (int)sqrt((double)T); a.is = p->image_size;
+    a.p = *p;
+    const float thr = p->dist_eps * p->dist_scale;               // float * float, kernel.cu:725
+    a.thr = (double)thr;
+    a.sqrt_thr = sqrt((double)thr);                              // sqrt(scalar_t), kernel.cu:747
+    a.softmax_sum0 = (double)expf(p->aggr_rgb_eps / p->aggr_rgb_gamma);   // exp of the float arguments, kernel.cu:729
+    return GENDR_OK;
+}
+
+unsigned long long gendr_workspace_bytes_f64(int B, int nf, int T, const gendr_params* p)
+{
+    if (!p || B < 0 || nf < 0 || T < 1 || p->image_size < 1) return 0;
+    return (unsigned long long)align256((size_t)B * nf * 27 * sizeof(double)) + 256;
+}
+
+int gendr_forward_f64(const double* faces, const double* textures, double* rgba, double* aggrs_info,
+                      void* workspace, int B, int nf, int T, const gendr_params* p, void* stream)
+{
+    const int v = gendr_validate(p, B, nf, T);
+    if (v != GENDR_OK) return v;
+    if (!rgba || !aggrs_info) return GENDR_E_NULL;
+    if (B == 0) return GENDR_OK;
+    if (!workspace) return GENDR_E_WORKSPACE;
+    const long total = (long)B * nf;
+    if (total > 0 && (!faces || !textures)) return GENDR_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    if (total > 0)
+        hipLaunchKernelGGL(f64::face_info_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, faces, static_cast<double*>(workspace), total);
+    f64::Args a;
+    fill_args_f64(a, faces, textures, workspace, B, nf, T, p);
+    a.rgba = rgba; a.aux = aggrs_info;
+    const long pixels = (long)B * p->image_size * p->image_size;
+    hipLaunchKernelGGL(f64::forward_kernel, dim3((unsigned)((pixels + f64::kThreadsD - 1) / f64::kThreadsD)), dim3(f64::kThreadsD), 0, s, a);
+    return check_launch();
+}
+
+int gendr_backward_f64(const double* faces, const double* textures, const double* rgba, const double* aggrs_info,
+                       const void* workspace, const double* grad_rgba, double* grad_faces, double* grad_textures,
+                       int B, int nf, int T, const gendr_params* p, void* stream)
+{
+    const int v = gendr_validate(p, B, nf, T);
+    if (v != GENDR_OK) return v;
+    if (B == 0 || nf == 0) return GENDR_OK;
+    if (!faces || !textures || !rgba || !aggrs_info || !grad_rgba || !grad_faces || !grad_textures) return GENDR_E_NULL;
+    if (!workspace) return GENDR_E_WORKSPACE;
+    f64::Args a;
+    fill_args_f64(a, faces, textures, const_cast<void*>(workspace), B, nf, T, p);
+    a.rgba = const_cast<double*>(rgba); a.aux = const_cast<double*>(aggrs_info);
+    a.grad_rgba = grad_rgba; a.grad_faces = grad_faces; a.grad_textures = grad_textures;
+    a.p.background_from_buffer = 0;
+    const long pixels = (long)B * p->image_size * p->image_size;
+    hipLaunchKernelGGL(f64::backward_kernel, dim3((unsigned)((pixels + f64::kThreadsD - 1) / f64::kThreadsD)), dim3(f64::kThreadsD), 0,
+                       (hipStream_t)stream, a);
+    return check_launch();
 }
 
 int gendr_selftest(int what, unsigned long long* report16, void* stream)

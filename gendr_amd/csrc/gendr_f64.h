@@ -1,0 +1,508 @@
+// gendr_f64.h -- float64 instantiation of the generalized soft rasterizer (gfx950).
+//
+// The reference dispatches its three kernels over AT_DISPATCH_FLOATING_TYPES (kernel.cu:1102,1117,1189), so float64
+// tensors are rendered and differentiated in double.  This is that instantiation for MI355X: every operation in double
+// (where the reference's literals promote a float expression to double, nothing changes for scalar_t = double), the
+// option scalars arrive as float exactly as the reference's kernel arguments do, and the few calls the reference makes
+// on explicit float (atanf, kernel.cu:258; expf of the float arguments eps / gamma, :729) stay float.
+//
+// Scope: correctness path for float64 users (gradient checks, conditioning studies), not the tuned path -- one lane
+// per pixel, faces walked in order (wave-uniform loads), the reference's own skip tests only (:747, :769, :784), the
+// gradients leave through global_atomic_add_f64.  The float32 kernels in gendr_kernels.h are the product's hot path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/gendr_hip.h"
+
+namespace gendr {
+namespace f64 {
+
+constexpr double kPiD = 3.14159265358979323846;
+
+// ---- distribution CDF, kernel.cu:243-363 (scalar_t = double) ------------------------------------------------------
+__device__ inline double cdf(int id, double sign, double x, double scale, double shape, double shift)
+{
+    switch (id) {
+    case 0:  return sign > 0 ? 1. : 0.;                                                       // :251-252
+    case 6:  return 1. / (1. + exp(-sign * x / scale));                                       // :254-255
+    case 8:  return (double)atanf((float)(sign * x / scale)) / kPiD + 0.5;                    // :257-258 explicit atanf
+    case 9:  return sign * x / scale / (1 + x / scale) / 2. + 0.5;                            // :260-261
+    case 5:  return sign < 0 ? 0.5 * exp(-x / scale) : 1. - 0.5 * exp(-x / scale);            // :263-268
+    case 1:                                                                                    // :270-277
+        if (sign * x / scale < -1) return 0.;
+        if (sign * x / scale < 1) return (sign * x) * 0.5 / scale + 0.5;
+        return 1.;
+    case 7:  return atan(tanh(sign * x / scale / 2.)) * 2. / kPiD + 0.5;                      // :279-280
+    case 2: {                                                                                  // :282-290
+        if (sign * x / scale < -1) return 0.;
+        if (sign * x / scale < 1) {
+            const double y = (sign * x) * 0.5 / scale + 0.5;
+            return 3 * y * y - 2 * y * y * y;
+        }
+        return 1.;
+    }
+    case 4:  return 0.5 * erfc(-(sign * x / scale) * 0.70710678118654752440);                  // :292-293 normcdf
+    case 14: case 15: {                                                                        // :295-319
+        double xs;
+        if (shape < 0.) return nan("");
+        if (id == 14) {
+            if (sign * x + shift * scale <= 0.) return 0.;
+            xs = sign * x + shift * scale;
+            if (xs / scale > 15.) return 1.;
+        } else {
+            if (sign * x - shift * scale >= 0.) return 1.;
+            xs = -(sign * x - shift * scale);
+            if (xs / scale > 15.) return 0.;
+        }
+        double kummers = 1. / tgamma(shape + 1.);
+        double factor = kummers;
+        for (int i = 1; i < 32; i++) {
+            factor *= xs / scale / (shape + i);
+            kummers += factor;
+        }
+        const double y = pow(xs / scale, shape) * exp(-xs / scale) * kummers;
+        return id == 14 ? y : 1. - y;
+    }
+    case 3:                                                                                    // :320-327
+        if (sign * x / scale < -1) return 0.;
+        if (sign * x / scale < 1)
+            return 0.5 + (sign * x * sqrt(scale * scale - x * x)) / (kPiD * scale * scale) + asin(sign * x / scale) / kPiD;
+        return 1.;
+    case 10: return exp(-exp(-sign * x / scale));                                              // :329-331
+    case 11: return 1. - exp(-exp(sign * x / scale));                                          // :333-335
+    case 16: case 17: {                                                                        // :337-347
+        double xs;
+        if (id == 16) {
+            if (sign * x + shift * scale <= 1e-6) return 0.;
+            xs = sign * x + shift * scale;
+        } else {
+            if (sign * x - shift * scale >= -1e-6) return 1.;
+            xs = -(sign * x - shift * scale);
+        }
+        const double y = erfc(sqrt(scale / 2. / xs));
+        return id == 16 ? y : 1. - y;
+    }
+    case 12: case 13: {                                                                        // :349-359
+        double xs;
+        if (id == 12) {
+            if (sign * x + shift * scale < 0.) return 0.;
+            xs = sign * x + shift * scale;
+        } else {
+            if (sign * x - shift * scale > 0.) return 1.;
+            xs = -(sign * x - shift * scale);
+        }
+        const double y = 1. - exp(-xs / scale);
+        return id == 12 ? y : 1. - y;
+    }
+    default: return nan("");                                                                   // :361-362
+    }
+}
+
+// ---- derivative of the CDF wrt x, kernel.cu:367-459 ---------------------------------------------------------------
+__device__ inline double pdf(int id, double sign, double x, double scale, double shape, double shift)
+{
+    switch (id) {
+    case 0:  return 0.;
+    case 6: { const double y = 1. / (1. + exp(-sign * x / scale)); return y * (1 - y) / scale; }
+    case 8:  return 1. / (kPiD * scale + kPiD / scale * x * x);
+    case 9:  return scale / (2. * (scale + x) * (scale + x));
+    case 5:  return 0.5 / scale * exp(-x / scale);
+    case 1:  return (sign * x / scale > -1 && sign * x / scale < 1) ? 0.5 / scale : 0.;
+    case 7:  return 1. / cosh(sign * x / scale) / kPiD / scale;
+    case 2:
+        if (sign * x / scale < -1. || sign * x / scale > 1.) return 0.;
+        return 0.75 / scale - 0.75 * (x * x) / pow(scale, 3.);
+    case 4:  return 1. / scale / sqrt(2. * kPiD) * exp(-0.5 * (x / scale) * (x / scale));
+    case 14: case 15: {
+        double xs;
+        if (shape < 0.) return nan("");
+        if (id == 14) {
+            if (sign * x + shift * scale <= 0.) return 0.;
+            xs = sign * x + shift * scale;
+        } else {
+            if (sign * x - shift * scale >= 0.) return 0.;
+            xs = -(sign * x - shift * scale);
+        }
+        return pow(1. / scale, shape) / tgamma(shape) * pow(xs, shape - 1.) * exp(-xs / scale);
+    }
+    case 3:
+        if (x / scale > 1) return 0.;
+        return 2. / kPiD / scale / scale * sqrt(scale * scale - x * x);
+    case 10: return exp(-((sign * x / scale) + exp(-(sign * x / scale)))) / scale;
+    case 11: return exp(-((-sign * x / scale) + exp(sign * x / scale))) / scale;
+    case 16: case 17: {
+        double xs;
+        if (id == 16) {
+            if (sign * x + shift * scale <= 1e-6) return 0.;
+            xs = sign * x + shift * scale;
+        } else {
+            if (sign * x - shift * scale >= -1e-6) return 0.;
+            xs = -(sign * x - shift * scale);
+        }
+        return sqrt(scale / 2. / kPiD) * exp(-scale / 2. / xs) / pow(xs, 3. / 2.);
+    }
+    case 12: case 13: {
+        double xs;
+        if (id == 12) {
+            if (sign * x + shift * scale < 0.) return 0.;
+            xs = sign * x + shift * scale;
+        } else {
+            if (sign * x - shift * scale > 0.) return 0.;
+            xs = -(sign * x - shift * scale);
+        }
+        return 1. / scale * exp(-xs / scale);
+    }
+    default: return nan("");
+    }
+}
+
+// ---- t-conorm fold step (:474-563) and closed-form partial (:567-614) ---------------------------------------------
+__device__ inline double tconorm(int id, double a_ex, double b_new, double p)
+{
+    const double a = 1. - a_ex, b = 1. - b_new;
+    switch (id) {
+    case 1: return a_ex > b_new ? a_ex : b_new;
+    case 2: return a_ex + b_new - a_ex * b_new;
+    case 3: return (a_ex + b_new) / (1 + a_ex * b_new);
+    case 4: if (p < 0.) return nan("");
+            return 1. - (a * b) / fmax(p + (1. - p) * (a + b - a * b), 1e-6);
+    case 5: if (p <= 0. || p == 1.) return nan("");
+            return 1. - log1p((pow(p, a) - 1.) * (pow(p, b) - 1.) / (p - 1.)) / log(p);
+    case 6: if (p <= 0.) return nan("");
+            return 1. - fmax(0., 1. - pow(pow(1. - a, p) + pow(1. - b, p), 1. / p));
+    case 7: if (p <= 0.) return nan("");
+            if (a < 1e-8 || b < 1e-8) return 1.;
+            return 1. - exp(-pow(pow(-log(a), p) + pow(-log(b), p), 1. / p));
+    case 8: if (p <= 0.) return nan("");
+            if (a < 1e-8 || b < 1e-8) return 1.;
+            return 1. - 1. / (1. + pow(pow((1. - a) / a, p) + pow((1. - b) / b, p), 1. / p));
+    case 9: if (p >= 0.) return nan("");
+            return 1. - pow(pow(a, p) + pow(b, p) - 1., 1. / p);
+    default: return nan("");
+    }
+}
+
+__device__ inline double tconorm_grad(int id, double A, double b, double p)
+{
+    switch (id) {
+    case 1: return A == b ? 1. : 0.;
+    case 2: return (1. - A) / fmax(1. - b, 1e-6);
+    case 3: return (1. - A * A) / fmax(1. - b * b, 1e-6);
+    case 4: return (1.0 - A) * (-A - p * (1.0 - A) + p + 1.0) / fmax((1.0 - b) * (-b - p * (1.0 - b) + p + 1.0), 1e-6);
+    case 5: { const double d = pow(p, 1.0 - b) - 1.0;
+              return pow(p, A - b) * (pow(p, 1.0 - A) - 1.0) / (d + copysign(1e-6, d)); }
+    case 6: if (A == 1.) return 0.;
+            return pow(b, p - 1.) * pow(A, 1. - p);
+    case 7: return (1. - A) * pow(-log1p(fmax(-b, -1. + 1e-6)), p - 1.) * pow(-log1p(fmax(-A, -1. + 1e-6)), 1. - p) / fmax(1. - b, 1e-6);
+    case 8: return (1. - A) * (1. - A) * pow(b / fmax(1. - b, 1e-6), p - 1.) * pow(A / fmax(1. - A, 1e-6), 1. - p)
+                   / fmax(1. - b, 1e-6) / fmax(1. - b, 1e-6);
+    case 9: { const double a1 = fmax(1. - A, 1e-6), b1 = fmax(1. - b, 1e-6);
+              return pow(b1, p - 1.) * pow(pow(b1, p) + pow(pow(-pow(b1, p) + pow(a1, p) + 1., 1. / p), p) - 1., (1. - p) / p); }
+    default: return nan("");
+    }
+}
+
+// ---- per-face preprocessing in the reference's layout [27] = inv[9], sym[9], obtuse[3], 0[6]  (:620-676) ----------
+__global__ __launch_bounds__(64) void face_info_kernel(const double* __restrict__ faces, double* __restrict__ info, long total)
+{
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= total) return;
+    const double* f = faces + 9 * i;
+    const double x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+    const double adj[9] = {y1 - y2, x2 - x1, x1 * y2 - x2 * y1,
+                           y2 - y0, x0 - x2, x2 * y0 - x0 * y2,
+                           y0 - y1, x1 - x0, x0 * y1 - x1 * y0};
+    double det = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+    det = det > 0 ? fmax(det, 1e-10) : fmin(det, -1e-10);
+    double* o = info + 27 * i;
+    for (int k = 0; k < 9; k++) o[k] = adj[k] / det;
+    for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 3; k++) o[9 + 3 * j + k] = f[3 * j] * f[3 * k] + f[3 * j + 1] * f[3 * k + 1] + 1;
+    const double px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+    for (int k = 18; k < 27; k++) o[k] = 0.;
+    for (int k = 0; k < 3; k++) {
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        if ((px[k1] - px[k]) * (px[k2] - px[k]) + (py[k1] - py[k]) * (py[k2] - py[k]) < 0) { o[18 + k] = 1; break; }
+    }
+}
+
+struct PairD { double w[3], t[3], sign, dx, dy, dis, frag; };
+
+__device__ inline bool inside_closed(const double* w) { return w[0] <= 1 && w[0] >= 0 && w[1] <= 1 && w[1] >= 0 && w[2] <= 1 && w[2] >= 0; }
+__device__ inline bool frontside(const double* f) { return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]); }
+__device__ inline void clip_bary(double* w)                                                    // :68-72
+{
+    for (int k = 0; k < 3; k++) w[k] = fmax(fmin(w[k], 1.), 0.);
+    const double s = fmax(w[0] + w[1] + w[2], 1e-5);
+    for (int k = 0; k < 3; k++) w[k] /= s;
+}
+
+// :76-165.  false: NaN barycentrics (the reference indexes with -1 there; the pair is dropped, DESIGN.md quirk iv)
+__device__ inline bool p2f_distance(PairD& q, const double* f, const double* info, double xp, double yp)
+{
+    const double* sym = info + 9;
+    const double* obt = info + 18;
+    const double* w = q.w;
+    if (w[0] > 0 && w[1] > 0 && w[2] > 0 && w[0] < 1 && w[1] < 1 && w[2] < 1) {
+        double best = 100000000, bx = 0, by = 0;
+        for (int k = 0; k < 3; k++) {
+            const int v0 = k, v1 = (k + 1) % 3, v2 = (k + 2) % 3;
+            double a0[3], t0[3];
+            for (int j = 0; j < 3; j++) a0[j] = sym[3 * v0 + j] - sym[3 * v1 + j];
+            t0[v0] = (w[0] * a0[0] + w[1] * a0[1] + w[2] * a0[2] - a0[v1]) / (a0[v0] - a0[v1]);
+            t0[v1] = 1 - t0[v0];
+            t0[v2] = 0;
+            for (int j = 0; j < 3; j++) t0[j] -= w[j];
+            const double dx = t0[0] * f[0] + t0[1] * f[3] + t0[2] * f[6];
+            const double dy = t0[0] * f[1] + t0[1] * f[4] + t0[2] * f[7];
+            const double d = dx * dx + dy * dy;
+            if (d < best) { best = d; bx = dx; by = dy; q.t[0] = t0[0]; q.t[1] = t0[1]; q.t[2] = t0[2]; }
+        }
+        q.dx = bx; q.dy = by; q.sign = 1;
+        return true;
+    }
+    int v0 = -1;
+    if (w[1] <= 0 && w[2] <= 0) {
+        v0 = 0;
+        if (obt[0] == 1 && (xp - f[0]) * (f[6] - f[0]) + (yp - f[1]) * (f[7] - f[1]) > 0) v0 = 2;
+    } else if (w[2] <= 0 && w[0] <= 0) {
+        v0 = 1;
+        if (obt[1] == 1 && (xp - f[3]) * (f[0] - f[3]) + (yp - f[4]) * (f[1] - f[4]) > 0) v0 = 0;
+    } else if (w[0] <= 0 && w[1] <= 0) {
+        v0 = 2;
+        if (obt[2] == 1 && (xp - f[6]) * (f[3] - f[6]) + (yp - f[7]) * (f[4] - f[7]) > 0) v0 = 1;
+    } else if (w[0] <= 0) v0 = 1;
+    else if (w[1] <= 0) v0 = 2;
+    else if (w[2] <= 0) v0 = 0;
+    if (v0 < 0) {
+        if (w[0] != w[0] || w[1] != w[1] || w[2] != w[2]) return false;
+        int m = 0;
+        if (w[1] < w[m]) m = 1;
+        if (w[2] < w[m]) m = 2;
+        v0 = (m + 1) % 3;
+    }
+    const int v1 = (v0 + 1) % 3, v2 = (v0 + 2) % 3;
+    double a0[3];
+    for (int j = 0; j < 3; j++) a0[j] = sym[3 * v0 + j] - sym[3 * v1 + j];
+    q.t[v0] = (w[0] * a0[0] + w[1] * a0[1] + w[2] * a0[2] - a0[v1]) / (a0[v0] - a0[v1]);
+    q.t[v1] = 1 - q.t[v0];
+    q.t[v2] = 0;
+    for (int k = 0; k < 3; k++) { q.t[k] = fmin(fmax(q.t[k], 0.), 1.); q.t[k] -= w[k]; }
+    q.dx = q.t[0] * f[0] + q.t[1] * f[3] + q.t[2] * f[6];
+    q.dy = q.t[0] * f[1] + q.t[1] * f[4] + q.t[2] * f[7];
+    q.sign = -1;
+    return true;
+}
+
+struct Args {
+    const double* faces; const double* textures; const double* info;
+    double* rgba; double* aux;
+    const double* grad_rgba; double* grad_faces; double* grad_textures;
+    int B, nf, T, R, is;
+    gendr_params p;
+    double thr, sqrt_thr, softmax_sum0;
+};
+
+// one (pixel, face) evaluation: false if skipped by :747 / :769 / :784
+__device__ inline bool eval_pair(PairD& q, const double* f, const double* info, double xp, double yp, const Args& a)
+{
+    const double xmax = fmax(fmax(f[0], f[3]), f[6]), xmin = fmin(fmin(f[0], f[3]), f[6]);
+    const double ymax = fmax(fmax(f[1], f[4]), f[7]), ymin = fmin(fmin(f[1], f[4]), f[7]);
+    if (xp > xmax + a.sqrt_thr || xp < xmin - a.sqrt_thr || yp > ymax + a.sqrt_thr || yp < ymin - a.sqrt_thr) return false;
+    for (int k = 0; k < 3; k++) q.w[k] = info[3 * k] * xp + info[3 * k + 1] * yp + info[3 * k + 2];
+    q.sign = 0; q.dx = 0; q.dy = 0; q.dis = 0; q.t[0] = q.t[1] = q.t[2] = 0;
+    if (a.p.dist_func == 0) {
+        q.frag = inside_closed(q.w) ? 1. : 0.;
+    } else {
+        if (!p2f_distance(q, f, info, xp, yp)) return false;
+        q.dis = q.dx * q.dx + q.dy * q.dy;
+        if (q.sign < 0 && q.dis >= a.thr) return false;
+        if (!a.p.dist_squared) q.dis = sqrt(q.dis);
+        q.frag = cdf(a.p.dist_func, q.sign, q.dis, (double)a.p.dist_scale, (double)a.p.dist_shape, (double)a.p.dist_shift);
+    }
+    return !(q.frag <= 0.000001);
+}
+
+// texel a pair reads in surface mode (:176-185) with this build's handling of the reference's out-of-block index
+__device__ inline long resolve_texel(const double* w, const Args& a, long face_lin, int& own)
+{
+    const int R = a.R, T = a.T;
+    auto index = [&](bool clamp) {
+        int wx = (int)(w[0] * R), wy = (int)(w[1] * R);
+        if (clamp) { wx = min(wx, R - 1); wy = min(wy, R - 1); }
+        if ((w[0] + w[1]) * R - wx - wy <= 1) return wy * R + wx;
+        return (R - 1 - wy) * R + (R - 1 - wx);
+    };
+    if (a.p.texel_mode == 1) {
+        const int idx = max(0, min(index(true), T - 1));
+        own = idx;
+        return face_lin * T + idx;
+    }
+    int idx = index(false);
+    long at = face_lin * T + idx;
+    if (at >= (long)a.B * a.nf * T || at < 0) {
+        idx = max(0, min(index(true), T - 1));
+        own = -1;
+        return face_lin * T + idx;
+    }
+    own = (idx >= 0 && idx < T) ? idx : -1;
+    return at;
+}
+
+constexpr int kThreadsD = 256;
+
+// forward, kernel.cu:680-862: one lane per pixel
+__global__ __launch_bounds__(kThreadsD) void forward_kernel(const Args a)
+{
+    const long P = (long)a.is * a.is;
+    const long i = (long)blockIdx.x * kThreadsD + threadIdx.x;
+    if (i >= (long)a.B * P) return;
+    const int bn = (int)(i / P);
+    const long pn = i - (long)bn * P;
+    const int row = (int)(pn / a.is), xi = (int)(pn - (long)row * a.is);
+    const int yi = a.is - 1 - row;
+    const double yp = (2. * yi + 1. - a.is) / a.is, xp = (2. * xi + 1. - a.is) / a.is;
+    const bool soft = a.p.aggr_rgb_func == 1;
+    double col[4] = {1, 1, 1, 0};
+    double ssum = a.softmax_sum0, smax = (double)a.p.aggr_rgb_eps;
+    double bg[3];
+    for (int k = 0; k < 3; k++) {
+        bg[k] = a.p.background_from_buffer ? a.rgba[((long)bn * 4 + k) * P + pn] : (double)a.p.background[k];
+        col[k] = soft ? bg[k] * ssum : bg[k];
+    }
+    double depth_min = 10000000;
+    int face_min = -1;
+    const double gam = (double)a.p.aggr_rgb_gamma;
+    for (int fn = 0; fn < a.nf; fn++) {
+        const long fl = (long)bn * a.nf + fn;
+        const double* f = a.faces + 9 * fl;
+        const double* info = a.info + 27 * fl;
+        PairD q;
+        if (!eval_pair(q, f, info, xp, yp, a)) continue;
+        if (a.p.aggr_alpha_func == 0) { if (q.frag > 0.5) col[3] = 1; }
+        else col[3] = tconorm(a.p.aggr_alpha_func, col[3], q.frag, (double)a.p.aggr_alpha_t_conorm_p);
+        double wc[3] = {q.w[0], q.w[1], q.w[2]};
+        clip_bary(wc);
+        const double zp = 1. / (wc[0] / f[2] + wc[1] / f[5] + wc[2] / f[8]);
+        if (zp < (double)a.p.near_ || zp > (double)a.p.far_) continue;
+        const double* tex = a.textures + fl * a.T * 3;
+        if (!soft) {
+            if (zp < depth_min && inside_closed(q.w) && (a.p.double_side || frontside(f))) {
+                depth_min = zp;
+                face_min = fn;
+                if (a.p.texture_type == 0) {
+                    int own;
+                    const long at = resolve_texel(wc, a, fl, own);
+                    for (int k = 0; k < 3; k++) col[k] = a.textures[at * 3 + k];
+                } else {
+                    for (int k = 0; k < 3; k++) col[k] = wc[0] * tex[k] + wc[1] * tex[3 + k] + wc[2] * tex[6 + k];
+                }
+            }
+        } else if (frontside(f) || a.p.double_side) {
+            const double zn = ((double)a.p.far_ - zp) / (double)(a.p.far_ - a.p.near_);
+            double edz = 1;
+            if (zn > smax) { edz = exp((smax - zn) / gam); smax = zn; }
+            const double ez = exp((zn - smax) / gam);
+            ssum = edz * ssum + ez * q.frag;
+            long at = 0; int own;
+            if (a.p.texture_type == 0) at = resolve_texel(wc, a, fl, own);
+            for (int k = 0; k < 3; k++) {
+                const double ck = a.p.texture_type == 0 ? a.textures[at * 3 + k]
+                                                         : wc[0] * tex[k] + wc[1] * tex[3 + k] + wc[2] * tex[6 + k];
+                col[k] = edz * col[k] + ez * q.frag * ck;
+            }
+        }
+    }
+    a.rgba[((long)bn * 4 + 3) * P + pn] = col[3];
+    if (!soft) {
+        for (int k = 0; k < 3; k++) a.rgba[((long)bn * 4 + k) * P + pn] = face_min != -1 ? col[k] : bg[k];
+        a.aux[((long)bn * 2 + 0) * P + pn] = depth_min;
+        a.aux[((long)bn * 2 + 1) * P + pn] = (double)face_min;
+    } else {
+        for (int k = 0; k < 3; k++) a.rgba[((long)bn * 4 + k) * P + pn] = col[k] / ssum;
+        a.aux[((long)bn * 2 + 0) * P + pn] = ssum;
+        a.aux[((long)bn * 2 + 1) * P + pn] = smax;
+    }
+}
+
+// backward, kernel.cu:866-1065: one lane per pixel, gradients by fp64 atomics
+__global__ __launch_bounds__(kThreadsD) void backward_kernel(const Args a)
+{
+    const long P = (long)a.is * a.is;
+    const long i = (long)blockIdx.x * kThreadsD + threadIdx.x;
+    if (i >= (long)a.B * P) return;
+    const int bn = (int)(i / P);
+    const long pn = i - (long)bn * P;
+    const int row = (int)(pn / a.is), xi = (int)(pn - (long)row * a.is);
+    const int yi = a.is - 1 - row;
+    const double yp = (2. * yi + 1 - a.is) / a.is, xp = (2. * xi + 1 - a.is) / a.is;
+    const bool soft = a.p.aggr_rgb_func == 1;
+    const double ssum = a.aux[((long)bn * 2 + 0) * P + pn], smax = a.aux[((long)bn * 2 + 1) * P + pn];
+    double g[4], out[4];
+    for (int k = 0; k < 4; k++) { g[k] = a.grad_rgba[((long)bn * 4 + k) * P + pn]; out[k] = a.rgba[((long)bn * 4 + k) * P + pn]; }
+    const double gam = (double)a.p.aggr_rgb_gamma;
+    for (int fn = 0; fn < a.nf; fn++) {
+        const long fl = (long)bn * a.nf + fn;
+        const double* f = a.faces + 9 * fl;
+        const double* info = a.info + 27 * fl;
+        PairD q;
+        if (!eval_pair(q, f, info, xp, yp, a)) continue;
+        double gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double C_xy = 0;
+        double C_alpha = g[3];
+        if (a.p.aggr_alpha_func != 0) C_alpha *= tconorm_grad(a.p.aggr_alpha_func, out[3], q.frag, (double)a.p.aggr_alpha_t_conorm_p);
+        C_xy += C_alpha;
+        double w[3] = {q.w[0], q.w[1], q.w[2]};
+        clip_bary(w);
+        const double zp = 1. / (w[0] / f[2] + w[1] / f[5] + w[2] / f[8]);
+        if (zp < (double)a.p.near_ || zp > (double)a.p.far_) continue;
+        double* gtex = a.grad_textures + fl * a.T * 3;
+        const double* tex = a.textures + fl * a.T * 3;
+        if (!soft) {
+            if ((double)fn == smax) {
+                if (a.p.texture_type == 0) {
+                    int own;
+                    (void)resolve_texel(w, a, fl, own);
+                    if (own >= 0) for (int k = 0; k < 3; k++) unsafeAtomicAdd(gtex + 3 * own + k, g[k]);
+                } else {
+                    for (int k = 0; k < 3; k++)
+                        for (int j = 0; j < 3; j++) unsafeAtomicAdd(gtex + 3 * j + k, w[j] * g[k]);
+                }
+            }
+        } else if (frontside(f) || a.p.double_side) {
+            double C_rgb = 0;
+            const double zn = ((double)a.p.far_ - zp) / (double)(a.p.far_ - a.p.near_);
+            const double zs = q.frag * exp((zn - smax) / gam) / ssum;
+            long at = 0; int own = -1;
+            if (a.p.texture_type == 0) at = resolve_texel(w, a, fl, own);
+            for (int k = 0; k < 3; k++) {
+                if (a.p.texture_type == 0) { if (own >= 0) unsafeAtomicAdd(gtex + 3 * own + k, zs * g[k]); }
+                else for (int j = 0; j < 3; j++) unsafeAtomicAdd(gtex + 3 * j + k, zs * (w[j] * g[k]));
+                const double ck = a.p.texture_type == 0 ? a.textures[at * 3 + k] : w[0] * tex[k] + w[1] * tex[3 + k] + w[2] * tex[6 + k];
+                C_rgb += g[k] * (ck - out[k]);
+            }
+            C_rgb *= zs;
+            C_xy += C_rgb / q.frag;
+            const double C_z = C_rgb / gam / (double)(a.p.near_ - a.p.far_) * zp * zp;
+            gv[2] = C_z * w[0] / f[2] / f[2];
+            gv[5] = C_z * w[1] / f[5] / f[5];
+            gv[8] = C_z * w[2] / f[8] / f[8];
+        }
+        if (a.p.dist_func != 0) {                      // heaviside: D' = 0, defined as exactly 0 (DESIGN.md quirk i)
+            C_xy *= pdf(a.p.dist_func, q.sign, q.dis, (double)a.p.dist_scale, (double)a.p.dist_shape, (double)a.p.dist_shift);
+            for (int k = 0; k < 3; k++)
+                for (int l = 0; l < 2; l++) {
+                    const double dl = l == 0 ? q.dx : q.dy;
+                    if (a.p.dist_squared) gv[3 * k + l] = 2 * q.sign * C_xy * (q.t[k] + q.w[k]) * dl;
+                    else gv[3 * k + l] = (q.sign * C_xy * (q.t[k] + q.w[k]) * dl) / fmax(sqrt(q.dx * q.dx + q.dy * q.dy), 1e-6);
+                }
+        }
+        for (int k = 0; k < 9; k++)
+            if (gv[k] != 0.) unsafeAtomicAdd(a.grad_faces + fl * 9 + k, gv[k]);
+    }
+}
+
+}  // namespace f64
+}  // namespace gendr

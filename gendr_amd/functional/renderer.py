@@ -131,26 +131,29 @@ def _require_device(t, name):
 
 
 def native_forward(faces, textures, params, rgba=None, aggrs_info=None):
-    """faces [B,nf,9] / textures [B,nf,T,3], fp32 contiguous on one GPU.  Returns
-    (rgba [B,4,is,is], aggrs_info [B,2,is,is], face_records)."""
+    """faces [B,nf,9] / textures [B,nf,T,3], contiguous on one GPU, both float32 or both float64 (the float64
+    instantiation, reference ``kernel.cu:1102``).  Returns (rgba [B,4,is,is], aggrs_info [B,2,is,is], workspace)."""
     L = _native.lib()
     B, nf = faces.shape[0], faces.shape[1]
     T = textures.shape[2]
     isz = params.image_size
     check(L.gendr_validate(ctypes.byref(params), B, nf, T), 'gendr.render')
     dev = faces.device
+    dt = faces.dtype
+    f64 = dt == torch.float64
     if rgba is None:
-        rgba = torch.empty((B, 4, isz, isz), dtype=torch.float32, device=dev)
+        rgba = torch.empty((B, 4, isz, isz), dtype=dt, device=dev)
     if aggrs_info is None:
-        aggrs_info = torch.empty((B, 2, isz, isz), dtype=torch.float32, device=dev)
-    records = torch.empty((max(int(L.gendr_workspace_bytes(B, nf, T, ctypes.byref(params))), 256),),
-                          dtype=torch.uint8, device=dev)
+        aggrs_info = torch.empty((B, 2, isz, isz), dtype=dt, device=dev)
+    nbytes = (L.gendr_workspace_bytes_f64 if f64 else L.gendr_workspace_bytes)(B, nf, T, ctypes.byref(params))
+    records = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
     ev = PROFILE_EVENTS
     with torch.cuda.device(dev):
         if ev is not None and ev[0] is not None:
             ev[0].record()
-        check(L.gendr_forward(_ptr(faces), _ptr(textures), _ptr(rgba), _ptr(aggrs_info), _ptr(records),
-                              B, nf, T, ctypes.byref(params), _stream_ptr()), 'gendr_forward')
+        check((L.gendr_forward_f64 if f64 else L.gendr_forward)(
+            _ptr(faces), _ptr(textures), _ptr(rgba), _ptr(aggrs_info), _ptr(records),
+            B, nf, T, ctypes.byref(params), _stream_ptr()), 'gendr_forward')
         if ev is not None and ev[1] is not None:
             ev[1].record()
     return rgba, aggrs_info, records
@@ -161,24 +164,27 @@ def native_backward(faces, textures, rgba, aggrs_info, records, grad_rgba, param
     B, nf = faces.shape[0], faces.shape[1]
     T = textures.shape[2]
     dev = faces.device
+    dt = faces.dtype
+    f64 = dt == torch.float64
     if grad_faces is None and grad_textures is None:
         # one zero fill for both gradients (they are small: one launch instead of two)
         n_f, n_t = B * nf * 9, textures.numel()
         n_f_pad = (n_f + 63) // 64 * 64                    # keep grad_textures 256-byte aligned
-        flat = torch.zeros(n_f_pad + n_t, dtype=torch.float32, device=dev)
+        flat = torch.zeros(n_f_pad + n_t, dtype=dt, device=dev)
         grad_faces = flat[:n_f].view(B, nf, 9)
         grad_textures = flat[n_f_pad:].view(textures.shape)
     if grad_faces is None:
-        grad_faces = torch.zeros((B, nf, 9), dtype=torch.float32, device=dev)
+        grad_faces = torch.zeros((B, nf, 9), dtype=dt, device=dev)
     if grad_textures is None:
-        grad_textures = torch.zeros(textures.shape, dtype=torch.float32, device=dev)
+        grad_textures = torch.zeros(textures.shape, dtype=dt, device=dev)
     ev = PROFILE_EVENTS
     with torch.cuda.device(dev):
         if ev is not None:
             ev[2].record()
-        check(L.gendr_backward(_ptr(faces), _ptr(textures), _ptr(rgba), _ptr(aggrs_info), _ptr(records),
-                               _ptr(grad_rgba), _ptr(grad_faces), _ptr(grad_textures),
-                               B, nf, T, ctypes.byref(params), _stream_ptr()), 'gendr_backward')
+        check((L.gendr_backward_f64 if f64 else L.gendr_backward)(
+            _ptr(faces), _ptr(textures), _ptr(rgba), _ptr(aggrs_info), _ptr(records),
+            _ptr(grad_rgba), _ptr(grad_faces), _ptr(grad_textures),
+            B, nf, T, ctypes.byref(params), _stream_ptr()), 'gendr_backward')
         if ev is not None:
             ev[3].record()
     return grad_faces, grad_textures
@@ -221,8 +227,12 @@ class GenDRFunction(Function):
         ctx.tex_shape, ctx.tex_dtype = textures.shape, textures.dtype
 
         B, nf = face_vertices.shape[:2]
-        faces = face_vertices.detach().reshape(B, nf, 9).to(torch.float32).contiguous()
-        tex = textures.detach().to(device=faces.device, dtype=torch.float32).contiguous()
+        # float64 tensors are rendered in double, as the reference's AT_DISPATCH_FLOATING_TYPES does
+        # (kernel.cu:1102,1117,1189); everything else in float32
+        compute = torch.float64 if face_vertices.dtype == torch.float64 else torch.float32
+        ctx.compute_dtype = compute
+        faces = face_vertices.detach().reshape(B, nf, 9).to(compute).contiguous()
+        tex = textures.detach().to(device=faces.device, dtype=compute).contiguous()
         if tex.dim() != 4 or tex.shape[0] != B or tex.shape[1] != nf or tex.shape[3] != 3:
             raise ValueError('textures must be [B, nf, T, 3] matching face_vertices [B, nf, 3, 3]; got %s and %s'
                              % (tuple(textures.shape), tuple(face_vertices.shape)))
@@ -235,7 +245,7 @@ class GenDRFunction(Function):
     @once_differentiable
     def backward(ctx, grad_soft_colors):
         faces, tex, soft_colors, records, aggrs_info = ctx.saved_tensors
-        grad = grad_soft_colors.to(torch.float32).contiguous()
+        grad = grad_soft_colors.to(ctx.compute_dtype).contiguous()
         grad_faces, grad_textures = native_backward(faces, tex, soft_colors, aggrs_info, records, grad, ctx.params)
         grad_faces = grad_faces.reshape(ctx.fv_shape).to(ctx.fv_dtype)
         grad_textures = grad_textures.reshape(ctx.tex_shape).to(ctx.tex_dtype)

@@ -97,6 +97,17 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
                    float* grad_faces, float* grad_textures,
                    int B, int nf, int T, const gendr_params* p, void* stream);
 
+/* float64 instantiation of the two render calls: the reference dispatches its kernels over AT_DISPATCH_FLOATING_TYPES
+ * (kernel.cu:1102,1117,1189), so float64 tensors are computed in double.  Same arguments as gendr_forward /
+ * gendr_backward with double buffers; the workspace (gendr_workspace_bytes_f64) holds faces_info [B,nf,27] in double.
+ * A correctness path (one lane per pixel, the reference's own skip tests, fp64 atomics), not the tuned one. */
+unsigned long long gendr_workspace_bytes_f64(int B, int nf, int T, const gendr_params* p);
+int gendr_forward_f64(const double* faces, const double* textures, double* rgba, double* aggrs_info,
+                      void* workspace, int B, int nf, int T, const gendr_params* p, void* stream);
+int gendr_backward_f64(const double* faces, const double* textures, const double* rgba, const double* aggrs_info,
+                       const void* workspace, const double* grad_rgba, double* grad_faces, double* grad_textures,
+                       int B, int nf, int T, const gendr_params* p, void* stream);
+
 /* The reference's per-face preprocessing in its own layout, faces_info [B,nf,27] =
  * inv[9], sym[9], obt[3], 0[6] (kernel.cu:620-676, functional/renderer.py:139), for
  * callers of the pybind-shaped forward_render that inspect faces_info. */
