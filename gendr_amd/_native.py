@@ -61,7 +61,7 @@ EXPORTS = (
     "gendr_sigmoid_forward", "gendr_sigmoid_backward", "gendr_t_conorm_forward", "gendr_t_conorm_backward",
     "gendr_cull_radius", "gendr_project_faces", "gendr_project_faces_backward",
     "gendr_camera_rotation", "gendr_camera_rotation_backward",
-    "gendr_workspace_bytes_f64", "gendr_forward_f64", "gendr_backward_f64", "gendr_selftest", "gendr_light_faces", "gendr_light_faces_backward", "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
+    "gendr_silhouette_workspace_bytes", "gendr_silhouette_forward", "gendr_silhouette_backward", "gendr_workspace_bytes_f64", "gendr_forward_f64", "gendr_backward_f64", "gendr_selftest", "gendr_light_faces", "gendr_light_faces_backward", "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
 )
 
 _lib = None
@@ -100,6 +100,12 @@ def lib():
     L.gendr_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, pp, vp]
     L.gendr_backward.restype = i
     L.gendr_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, pp, vp]
+    L.gendr_silhouette_workspace_bytes.restype = ctypes.c_ulonglong
+    L.gendr_silhouette_workspace_bytes.argtypes = [i, i, pp]
+    L.gendr_silhouette_forward.restype = i
+    L.gendr_silhouette_forward.argtypes = [vp, vp, vp, vp, vp, i, i, pp, vp]
+    L.gendr_silhouette_backward.restype = i
+    L.gendr_silhouette_backward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, pp, vp]
     L.gendr_workspace_bytes_f64.restype = ctypes.c_ulonglong
     L.gendr_workspace_bytes_f64.argtypes = [i, i, i, pp]
     L.gendr_forward_f64.restype = i

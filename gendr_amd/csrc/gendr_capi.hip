@@ -61,6 +61,17 @@ const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_K(kGamma,       kYager,         1, 0, kTexVertex, C5F, C5B),   // C5
     GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // opt_shape / train_reconstruction soft renderer (hard RGB)
     GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),   // opt_shape hard renderer (opt_shape.py:148-159)
+    // alpha-only (silhouette) kernels, SURVEY f-4: what opt_shape / train_reconstruction actually consume
+    GENDR_SPECIALISE_K(kUniform,     kProbabilistic, kRgbNone, 0, kTexSurfaceN, w6, wa),
+    GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     kRgbNone, 0, kTexSurfaceN),
+};
+
+// alpha-only runtime-dispatch kernels, by the same four classes as kGeneric
+#define GENDR_SIL_ROW(D, A, K) \
+    { {D, A, kRgbNone, -1, kTexSurfaceN}, render_forward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN>, render_backward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN> }
+const KernelEntry kGenericSil[2][2] = {
+    { GENDR_SIL_ROW(-1, -1, wf), GENDR_SIL_ROW(-1, -2, wf) },
+    { GENDR_SIL_ROW(-2, -1, wa), GENDR_SIL_ROW(-2, -2, wl) },
 };
 
 // Runtime-dispatch kernels, four classes by what has to be compiled in: the 13 "light" distributions or all 18, the 5
@@ -79,13 +90,15 @@ const KernelEntry kGeneric[2][2][3] = {
     { GENDR_GENERIC_CLASS(-2, -1, wa), GENDR_GENERIC_CLASS(-2, -2, wl) },
 };
 
-const KernelEntry& pick_kernel(const gendr_params* p, int texm)
+const KernelEntry& pick_kernel(const gendr_params* p, int texm, bool silhouette = false)
 {
+    const int rgb = silhouette ? kRgbNone : p->aggr_rgb_func;
     for (const KernelEntry& e : kSpecialised) {
-        if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == p->aggr_rgb_func &&
+        if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == rgb &&
             e.key.sq == (p->dist_squared ? 1 : 0) && e.key.texm == texm)
             return e;
     }
+    if (silhouette) return kGenericSil[is_light_dist(p->dist_func) ? 1 : 0][is_light_alpha(p->aggr_alpha_func) ? 1 : 0];
     return kGeneric[is_light_dist(p->dist_func) ? 1 : 0][is_light_alpha(p->aggr_alpha_func) ? 1 : 0][texm];
 }
 
@@ -339,6 +352,66 @@ float gendr_cull_radius(const gendr_params* p)
     return r;
 }
 
+// ---- alpha-only rendering (SURVEY f-4) ------------------------------------------------------------------------------
+// The workspace is laid out for T = 4 surface texels, i.e. texture mode kTexSurfaceN: records without texels; no
+// texture pointer is ever dereferenced by the alpha-only kernels.
+static const int kSilT = 4;
+
+unsigned long long gendr_silhouette_workspace_bytes(int B, int nf, const gendr_params* p)
+{
+    if (!p || p->texture_type != 0) return 0;
+    return gendr_workspace_bytes(B, nf, kSilT, p);
+}
+
+int gendr_silhouette_forward(const float* faces, float* alpha, void* workspace, const float* target, float* iou_sums,
+                             int B, int nf, const gendr_params* p, void* stream)
+{
+    if (p && p->texture_type != 0) return GENDR_E_TEXTURE_TYPE;
+    const int v = gendr_validate(p, B, nf, kSilT);
+    if (v != GENDR_OK) return v;
+    if (!alpha || (target && !iou_sums)) return GENDR_E_NULL;
+    if (B == 0) return GENDR_OK;
+    if (!workspace) return GENDR_E_WORKSPACE;
+    if ((long)B * nf > 0 && !faces) return GENDR_E_NULL;
+    const int e = gendr_face_setup(faces, faces /* never read in this texture mode */, workspace, B, nf, kSilT, p, stream);
+    if (e != GENDR_OK) return e;
+    if (target && hipMemsetAsync(iou_sums, 0, (size_t)B * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return GENDR_E_LAUNCH;
+    RenderArgs a;
+    const int texm = fill_args(a, workspace, nullptr, B, nf, kSilT, p);
+    a.rgba = alpha;
+    a.target = target;
+    a.iou_sums = iou_sums;
+    a.p.background_from_buffer = 0;
+    const KernelEntry& k = pick_kernel(p, texm, true);
+    hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+int gendr_silhouette_backward(const float* alpha, const void* workspace, const float* grad_alpha,
+                              const float* target, const float* grad_iou, float* grad_faces,
+                              int B, int nf, const gendr_params* p, void* stream)
+{
+    if (p && p->texture_type != 0) return GENDR_E_TEXTURE_TYPE;
+    const int v = gendr_validate(p, B, nf, kSilT);
+    if (v != GENDR_OK) return v;
+    if (B == 0 || nf == 0) return GENDR_OK;
+    if (!alpha || !grad_faces) return GENDR_E_NULL;
+    if (!grad_alpha && !(target && grad_iou)) return GENDR_E_NULL;
+    if (!workspace) return GENDR_E_WORKSPACE;
+    RenderArgs a;
+    const int texm = fill_args(a, workspace, nullptr, B, nf, kSilT, p);
+    a.rgba = const_cast<float*>(alpha);
+    a.grad_rgba = grad_alpha;
+    a.target = target;
+    a.grad_iou = grad_alpha ? nullptr : grad_iou;
+    a.grad_faces = grad_faces;
+    a.grad_textures = grad_faces;            // never written: the alpha-only kernels have no texture term
+    a.p.background_from_buffer = 0;
+    const KernelEntry& k = pick_kernel(p, texm, true);
+    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
 // ---- float64 instantiation (kernel.cu:1102,1117,1189 AT_DISPATCH_FLOATING_TYPES) ------------------------------------
 static int fill_args_f64(f64::Args& a, const double* faces, const double* textures, void* workspace,
                          int B, int nf, int T, const gendr_params* p)
@@ -442,11 +515,11 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     const float sthr = sqrtf(p->dist_eps * p->dist_scale);       // sqrt(threshold), kernel.cu:725,747
     const float cull_r = gendr_cull_radius(p);
     if (texm == kTexSurface1)
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_);
     else if (texm == kTexVertex)
-        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol);
+        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_);
     else
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_);
     int e = check_launch();
     if (e != GENDR_OK) return e;
     // one workgroup per (image, 64x64 super-tile): tile masks and the tile queues

@@ -143,6 +143,9 @@ constexpr int kRecXY    = 36;   // x0 y0 x1 y1 x2 y2
 constexpr int kRecRZ    = 42;   // 3 doubles: 1 / z_k   (:809, :1027-1029)
 constexpr int kRecTex   = 48;   // TEXM 0: own rgb, next-face rgb ; TEXM 1: 3 vertex colours ; TEXM 2: nothing
 constexpr int kRecStage1 = 20, kRecStage3 = 42;
+constexpr int kBitFront = 8;      // record flag bits next to the obtuse-corner bits 1, 2, 4
+constexpr int kBitDepthSafe = 16; // all three vertex depths well inside [near, far]: the clipped depth cannot fail :810 / :994
+constexpr int kRgbNone = 2;       // RGB template value of the alpha-only kernels (SURVEY f-4): no colour, depth or softmax state
 
 // texture modes of the kernels
 constexpr int kTexSurface1 = 0;   // texture_type surface, T == 1 (default Mesh texture): texels staged in the record
@@ -187,6 +190,10 @@ struct RenderArgs {
     const float*  textures;     // [B,nf,T,3]
     float*        rgba;         // [B,4,is,is]
     float*        aux;          // [B,2,is,is]
+    // silhouette (alpha-only) kernels, RGB == kRgbNone: `rgba` / `grad_rgba` are single planes [B,is,is]
+    const float*  target;       // [B,is,is] target silhouettes of the fused IoU epilogue, or NULL
+    float*        iou_sums;     // [B,2]: sum(alpha * target), sum(alpha * (1 - target)) per view (forward, accumulated)
+    const float*  grad_iou;     // [B,2]: d loss / d (those two sums) per view (backward); NULL: grad_rgba is the alpha gradient
     const float*  grad_rgba;    // backward only
     float*        grad_faces;   // backward only
     float*        grad_textures;
@@ -269,7 +276,7 @@ template <int TEXM>
 __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const float* __restrict__ faces, const float* __restrict__ textures,
     float* __restrict__ boxes, float* __restrict__ records,
-    long total_faces, float sthr, float cull_r, int* __restrict__ control, int ncontrol)
+    long total_faces, float sthr, float cull_r, int* __restrict__ control, int ncontrol, float near_, float far_)
 {
     constexpr int REC = record_floats(TEXM);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // launched with one wavefront per workgroup
@@ -366,7 +373,12 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     r[kRecBox + 0] = xlo; r[kRecBox + 1] = xhi; r[kRecBox + 2] = ylo; r[kRecBox + 3] = yhi;
 #pragma unroll
     for (int k = 0; k < 9; k++) r[kRecInv + k] = g.inv[k];
-    r[kRecBits] = __int_as_float(g.obt | (g.front << 3));
+    // The clipped, renormalised barycentrics are >= 0 and sum to 1 (at least one raw weight is >= 1/3), so the
+    // perspective depth 1 / sum(w_k / z_k) lies between the smallest and the largest vertex depth up to rounding:
+    // with a 1e-4 margin on both sides the near / far test (:810, :994) can never fire for this face.
+    const float zlo = fminf(fminf(f[2], f[5]), f[8]), zhi = fmaxf(fmaxf(f[2], f[5]), f[8]);
+    const int depth_safe = (zlo > 0.f && zlo >= near_ * 1.0001f && zhi <= far_ * 0.9999f) ? kBitDepthSafe : 0;
+    r[kRecBits] = __int_as_float(g.obt | (g.front << 3) | depth_safe);
     r[kRecWCull + 0] = wcull[0]; r[kRecWCull + 1] = wcull[1]; r[kRecWCull + 2] = wcull[2];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -1168,6 +1180,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
+    constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` is one plane [B,is,is], nothing else is written
 
     TileWalk tw;
     walk_init(tw, a, WAVES);
@@ -1179,6 +1192,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         TileCtx t;
         tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]));
         if (!t.valid) continue;
+        if constexpr (kSil) { a.rgba[(long)t.b * P + t.pix] = 0.f; continue; }
         float* out = a.rgba + (long)t.b * 4 * P + t.pix;
         float* aux = a.aux + (long)t.b * 2 * P + t.pix;
         out[3 * P] = 0.f;
@@ -1214,7 +1228,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     float bg[3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
-        bg[k] = (a.p.background_from_buffer && t.valid) ? a.rgba[((long)t.b * 4 + k) * P + t.pix] : a.p.background[k];
+        bg[k] = kSil ? 0.f : ((a.p.background_from_buffer && t.valid) ? a.rgba[((long)t.b * 4 + k) * P + t.pix] : a.p.background[k]);
     float alpha = 0.f;
     float ssum = a.softmax_sum0, smax = a.p.aggr_rgb_eps;
     float col[3];
@@ -1247,7 +1261,10 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             barycentrics(q, r, pxp, pyp);
             FwdRes res;
             res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fn = fn; res.pad1 = 0;
-            if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) {
+            if (kSil) {
+                // alpha needs the fragment only: the reference folds it before it looks at the depth (:795-810)
+                if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) { res.flags = kFlagContrib; res.frag = q.frag; }
+            } else if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) {
                 gather_record<kGatherB0, REC / 4>(r, rg);
                 res.flags = kFlagContrib;
                 res.frag = q.frag;
@@ -1255,7 +1272,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
                 const float zp = clip_and_depth(q, r, wc);
                 if (!(zp < a.p.near_ || zp > a.p.far_)) {                         // :810
                     res.flags |= kFlagDepthOk;
-                    const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
+                    const bool front = (__float_as_int(r[kRecBits]) & kBitFront) != 0;
                     const bool eligible = rgb_soft ? (front || a.p.double_side)                         // :825
                                                    : (inside_closed(q) && (a.p.double_side || front));  // :816
                     if (eligible) {
@@ -1288,6 +1305,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             } else {
                 alpha = tconorm_fold_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
             }
+            if constexpr (kSil) continue;
             if (!(res.flags & kFlagRgb)) continue;
             if (!rgb_soft) {                                                     // :815-822
                 if (res.z < depth_min) {
@@ -1343,7 +1361,21 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         if (!flush) emit(m);
     });
 
-    if (t.valid) {
+    if constexpr (kSil) {
+        // alpha plane, and the tile's share of the fused IoU sums (opt_shape.py:20-24: intersect = sum(a t),
+        // union = sum(a + t - a t) = sum(t) + sum(a (1 - t)); unlisted tiles have a = 0 and add nothing)
+        if (t.valid) a.rgba[(long)t.b * P + t.pix] = alpha;
+        if (a.target) {
+            const float tv = t.valid ? a.target[(long)t.b * P + t.pix] : 0.f;
+            float s1 = t.valid ? alpha * tv : 0.f, s2 = t.valid ? alpha * (1.f - tv) : 0.f;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+            if (lane == 0) {
+                if (s1 != 0.f) unsafeAtomicAdd(a.iou_sums + 2 * t.b, s1);
+                if (s2 != 0.f) unsafeAtomicAdd(a.iou_sums + 2 * t.b + 1, s2);
+            }
+        }
+    } else if (t.valid) {
         // epilogue, kernel.cu:845-861
         float* out = a.rgba + (long)t.b * 4 * P + t.pix;
         float* aux = a.aux + (long)t.b * 2 * P + t.pix;
@@ -1424,6 +1456,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
+    constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` / `grad_rgba` are single planes, see RenderArgs
 
     TileWalk tw;
     walk_init(tw, a, WAVES);
@@ -1438,7 +1471,18 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 #pragma unroll
         for (int k = 0; k < 4; k++) { pi.g[k] = 0.f; pi.out[k] = 0.f; }
         pi.ssum = 1.f; pi.smax = 0.f; pi.xp = t.xp; pi.yp = t.yp;
-        if (t.valid) {
+        if (kSil) {
+            if (t.valid) {
+                pi.out[3] = a.rgba[(long)t.b * P + t.pix];
+                if (a.grad_iou) {
+                    // d loss / d alpha of the fused IoU sums: g1 * t + g2 * (1 - t)
+                    const float tv = a.target[(long)t.b * P + t.pix];
+                    pi.g[3] = a.grad_iou[2 * t.b] * tv + a.grad_iou[2 * t.b + 1] * (1.f - tv);
+                } else {
+                    pi.g[3] = a.grad_rgba[(long)t.b * P + t.pix];
+                }
+            }
+        } else if (t.valid) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 pi.g[k] = a.grad_rgba[((long)t.b * 4 + k) * P + t.pix];
@@ -1480,7 +1524,9 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             for (int k = 0; k < NT; k++) gt[k] = 0.f;
             bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp);
             if (live) {
-                gather_record<kGatherB0, REC / 4>(r, rg);
+                // alpha only, and this face's depth cannot fail the near / far test (see face_setup_kernel): no depth stage
+                const bool need_depth = !(kSil && (__float_as_int(r[kRecBits]) & kBitDepthSafe));
+                if (need_depth) gather_record<kGatherB0, REC / 4>(r, rg);
                 // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
                 float C_xy = 0.f;
                 float C_alpha = px.g[3];
@@ -1494,11 +1540,16 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                 C_xy += C_alpha;
 
                 float wc[3];
-                const float zp = clip_and_depth(q, r, wc);
-                live = !(zp < a.p.near_ || zp > a.p.far_);                      // :994 drops the whole pair
+                float zp = 0.f;
+                if (need_depth) {
+                    zp = clip_and_depth(q, r, wc);
+                    live = !(zp < a.p.near_ || zp > a.p.far_);                  // :994 drops the whole pair
+                }
                 if (live) {
-                    const bool front = (__float_as_int(r[kRecBits]) & 8) != 0;
-                    if (!rgb_soft) {                                            // :997-1004
+                    const bool front = (__float_as_int(r[kRecBits]) & kBitFront) != 0;
+                    if constexpr (kSil) {
+                        // no colour term: C_xy stays the alpha partial
+                    } else if (!rgb_soft) {                                     // :997-1004
                         if ((float)fn == px.smax) {
                             if constexpr (TEXM == kTexVertex) {
 #pragma unroll

@@ -5,3 +5,4 @@ from .lighting import ambient_lighting, directional_lighting
 from .obj_io import load_obj, save_obj, save_voxel, voxelization
 from .projection import CameraFacesFunction, ProjectFacesFunction, project_faces, look_at_faces, look_faces
 from .shading import LightFacesFunction, light_faces, light_params
+from .silhouette import render_silhouette, silhouette_iou, silhouette_iou_loss, SilhouetteFunction, SilhouetteIoUFunction

@@ -52,3 +52,31 @@ class GenDR(nn.Module):
 
     def forward(self, mesh):
         return self.forward_tensors(mesh.face_vertices, mesh.face_textures)
+
+    # ---- alpha-only rendering (SURVEY f-4; not part of the reference's surface) -------------------------------------
+    def _silhouette_options(self):
+        o = self._options()
+        for k in ('aggr_rgb_func', 'aggr_rgb_eps', 'aggr_rgb_gamma', 'double_side', 'texture_type'):
+            o.pop(k)
+        return o
+
+    def silhouette(self, mesh):
+        """``self(mesh)[:, 3]`` from the alpha-only kernels (no RGB / aggrs_info planes); anti-aliasing as in forward."""
+        from .functional.silhouette import render_silhouette
+        scale = 2 if self.anti_aliasing else 1
+        alpha = render_silhouette(mesh.face_vertices, image_size=self.image_size * scale, **self._silhouette_options())
+        if self.anti_aliasing:
+            alpha = F.avg_pool2d(alpha[:, None], kernel_size=2, stride=2)[:, 0]
+        return alpha
+
+    def silhouette_iou_loss(self, mesh, target, eps=1e-6):
+        """``iou_loss(self(mesh)[:, 3], target)`` (``experiments/opt_shape.py:20-24``) with the two IoU sums accumulated
+        in the forward kernel and the gradient formed in the backward kernel.  Without anti-aliasing only."""
+        from .functional.silhouette import silhouette_iou_loss
+        if self.anti_aliasing:
+            from .functional.silhouette import render_silhouette
+            a = self.silhouette(mesh)
+            dims = tuple(range(1, a.ndimension()))
+            inter = (a * target).sum(dims)
+            return (1. - inter / ((a + target - a * target).sum(dims) + eps)).mean()
+        return silhouette_iou_loss(mesh.face_vertices, target, eps=eps, image_size=self.image_size, **self._silhouette_options())

@@ -97,6 +97,24 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
                    float* grad_faces, float* grad_textures,
                    int B, int nf, int T, const gendr_params* p, void* stream);
 
+/* ---- alpha-only rendering with the silhouette loss fused into the epilogue -------------------------
+ * The experiment scripts consume only the alpha channel (opt_shape.py:257,296-303; train_reconstruction.py:41-46).
+ * These two calls render / differentiate that channel alone: no RGB or aggrs_info planes are written or read (4 B per
+ * pixel out instead of 24, 8 B per pixel in instead of 40), no depth / colour / softmax work per pair, no textures.
+ *   alpha      [B,is,is]  out / in   == channel 3 of gendr_forward's rgba, bit for bit
+ *   target     [B,is,is]  in, optional: target silhouettes; then iou_sums [B,2] receives per view
+ *              sum(alpha * target) and sum(alpha * (1 - target)), from which intersect = sums[0] and
+ *              union = sum(target) + sums[1] of iou_loss (opt_shape.py:20-24, train_reconstruction.py:30-36)
+ *   backward:  either grad_alpha [B,is,is] (d loss / d alpha), or target + grad_iou [B,2] (d loss / d iou_sums): then
+ *              the per-pixel gradient grad_iou[b,0] * t + grad_iou[b,1] * (1 - t) is formed on the fly.
+ *   grad_faces [B,nf,9] zero-filled by the caller; gradients are accumulated.  texture_type must be 0. */
+unsigned long long gendr_silhouette_workspace_bytes(int B, int nf, const gendr_params* p);
+int gendr_silhouette_forward(const float* faces, float* alpha, void* workspace, const float* target, float* iou_sums,
+                             int B, int nf, const gendr_params* p, void* stream);
+int gendr_silhouette_backward(const float* alpha, const void* workspace, const float* grad_alpha,
+                              const float* target, const float* grad_iou, float* grad_faces,
+                              int B, int nf, const gendr_params* p, void* stream);
+
 /* float64 instantiation of the two render calls: the reference dispatches its kernels over AT_DISPATCH_FLOATING_TYPES
  * (kernel.cu:1102,1117,1189), so float64 tensors are computed in double.  Same arguments as gendr_forward /
  * gendr_backward with double buffers; the workspace (gendr_workspace_bytes_f64) holds faces_info [B,nf,27] in double.
