@@ -93,6 +93,32 @@ def cpu_baseline_oracle(cfg, fv, tex, target_seconds=12.0):
                        % (n, isz, isz, fvn.shape[1], cores, tn))
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a container that sees
+    128 CPUs but is throttled to a quota runs a 128-thread PyTorch pool far slower than a right-sized one)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            a, b = f.read().split()[:2]
+            if a != 'max':
+                quota = float(a) / float(b)
+    except Exception:
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def _torch_baseline_worker(q, cfg, fv, tex, stride, threads, budget):
     """Child process: times 1 frame on every `stride`-th face; starts from a coarse sample and refines while the
     projected time fits the budget.  Puts (seconds, stride) or ('error', text)."""
@@ -110,8 +136,9 @@ def _torch_baseline_worker(q, cfg, fv, tex, stride, threads, budget):
             torch_ref.render(fv[:1, ::st].contiguous(), tex[:1, ::st].contiguous(), isz, grad=g, **opts)
             return time.perf_counter() - t0
 
-        st = max(stride, 16)
+        st = max(stride, 64)
         dt = run(st)
+        dt = run(st)                                  # the first call pays for thread-pool start-up and page faults
         while st > stride and dt * 2.2 < budget:
             st //= 2
             dt = run(st)
@@ -133,7 +160,7 @@ def cpu_baseline_torch(cfg, fv, tex, stride=4, timeout=200, budget=25.0):
         return None
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    threads = max(1, os.cpu_count() or 1)
+    threads = usable_cores()
     p = ctx.Process(target=_torch_baseline_worker, args=(q, cfg, fv[:1].cpu(), tex[:1].cpu(), stride, threads, budget))
     p.start()
     p.join(timeout)
@@ -149,8 +176,9 @@ def cpu_baseline_torch(cfg, fv, tex, stride=4, timeout=200, budget=25.0):
     nf = fv.shape[1]
     return dict(value=1.0 / (dt * st), unit='frames/s', cores=threads, kind='port',
                 sample='1 frame, every %dth of the %d faces (all-pairs evaluation, linear in faces), forward+backward, '
-                       'vectorised pure PyTorch (oracle/torch_ref.py), torch.set_num_threads(%d) = all host cores; %.1f s scaled x%d'
-                       % (st, nf, threads, dt, st))
+                       'vectorised pure PyTorch (oracle/torch_ref.py), torch.set_num_threads(%d) = all usable host cores '
+                       '(os.cpu_count() = %d, affinity / cgroup quota applied); %.1f s scaled x%d'
+                       % (st, nf, threads, os.cpu_count() or 0, dt, st))
 
 
 # ------------------------------------------------------------------------------------------------------------

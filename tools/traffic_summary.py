@@ -12,7 +12,7 @@ for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
         if r['Counter_Name'] != ctr or 'gendr' not in r['Kernel_Name']:
             continue
         name = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0].replace('gendr::', '')
-        name = re.sub(r'_w\d$', '', name)          # occupancy-capped variants of the render kernels
+        name = re.sub(r'_w[0-9a-z]$', '', name)          # occupancy-capped variants of the render kernels
         acc[name].append(float(r['Counter_Value']))
     vals[ctr] = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
 res = {'config': cfg, 'unit': 'bytes per launch', 'raw_kib': vals, 'hbm_bytes_per_launch': {}, 'read_bytes_corrected': {}, 'write_bytes': {},
