@@ -63,36 +63,6 @@ def algorithmic_bytes(P, nf, T):
 # ------------------------------------------------------------------------------------------------------------
 # CPU baselines (rank 0, N = 1 only; bounded samples)
 # ------------------------------------------------------------------------------------------------------------
-def cpu_baseline_oracle(cfg, fv, tex, target_seconds=12.0):
-    """Times the CPU oracle (oracle/, test infrastructure used here only as a reported baseline)
-    on a bounded sample of the same workload with all host cores."""
-    import numpy as np
-    import oracle
-    oracle.build()
-    isz = cfg['image_size']
-    opts = dict(cfg['opts'])
-    opts.setdefault('double_side', False)
-    oo = oracle.make_opts(image_size=isz, **opts)
-    cores = oracle.max_threads()
-    fvn = fv.cpu().numpy()
-    texn = tex.cpu().numpy()
-    rs = np.random.RandomState(1)
-
-    def run(n):
-        g = rs.randn(n, 4, isz, isz).astype(np.float32)
-        t0 = time.perf_counter()
-        fwd = oracle.forward(fvn[:n], texn[:n], oo)
-        oracle.backward(fwd, g, oo)
-        return time.perf_counter() - t0
-
-    t1 = run(1)
-    n = int(max(1, min(fvn.shape[0], target_seconds / max(t1, 1e-3))))
-    tn = run(n) if n > 1 else t1
-    return dict(value=n / tn, unit='frames/s', cores=cores, kind='port',
-                sample='%d frame(s) of the same workload (%dx%d, %d faces), forward+backward, C oracle with OpenMP on %d threads, %.1f s'
-                       % (n, isz, isz, fvn.shape[1], cores, tn))
-
-
 def usable_cores():
     """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a container that sees
     128 CPUs but is throttled to a quota runs a 128-thread PyTorch pool far slower than a right-sized one)."""
@@ -117,6 +87,36 @@ def usable_cores():
     if quota is not None:
         n = max(1, min(n, int(quota + 0.5)))
     return n
+
+
+def cpu_baseline_oracle(cfg, fv, tex, target_seconds=12.0):
+    """Times the CPU oracle (oracle/, test infrastructure used here only as a reported baseline)
+    on a bounded sample of the same workload with all host cores."""
+    import numpy as np
+    import oracle
+    oracle.build()
+    isz = cfg['image_size']
+    opts = dict(cfg['opts'])
+    opts.setdefault('double_side', False)
+    cores = min(oracle.max_threads(), usable_cores())          # OpenMP threads = cores the cgroup quota really grants
+    oo = oracle.make_opts(image_size=isz, num_threads=cores, **opts)
+    fvn = fv.cpu().numpy()
+    texn = tex.cpu().numpy()
+    rs = np.random.RandomState(1)
+
+    def run(n):
+        g = rs.randn(n, 4, isz, isz).astype(np.float32)
+        t0 = time.perf_counter()
+        fwd = oracle.forward(fvn[:n], texn[:n], oo)
+        oracle.backward(fwd, g, oo)
+        return time.perf_counter() - t0
+
+    t1 = run(1)
+    n = int(max(1, min(fvn.shape[0], target_seconds / max(t1, 1e-3))))
+    tn = run(n) if n > 1 else t1
+    return dict(value=n / tn, unit='frames/s', cores=cores, kind='port',
+                sample='%d frame(s) of the same workload (%dx%d, %d faces), forward+backward, C oracle with OpenMP on %d threads, %.1f s'
+                       % (n, isz, isz, fvn.shape[1], cores, tn))
 
 
 def _torch_baseline_worker(q, cfg, fv, tex, stride, threads, budget):

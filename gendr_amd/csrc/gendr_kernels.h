@@ -67,6 +67,21 @@
 #define GENDR_SPLIT_MIN 8
 #endif
 
+#ifndef GENDR_MFMA_SUMS
+#define GENDR_MFMA_SUMS 0      // 1: the per-face sums of the backward partials run on the matrix pipe (see render_backward_body).
+                               // Measured at C2: correct and deterministic, but 175 us instead of 137 us for the backward kernel
+                               // (one or two accumulators alike), so the scalar LDS loop stays the default.
+#endif
+
+#ifndef GENDR_TIMERS
+#define GENDR_TIMERS 0         // 1: the backward kernel accumulates its wave-time per phase (diagnostic build, tools/phase_timers.py)
+#endif
+#if GENDR_TIMERS
+#define GENDR_T(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define GENDR_T(i) do {} while (0)
+#endif
+
 #ifndef GENDR_BIN_EDGE
 #define GENDR_BIN_EDGE 0   // 1: the binning kernel also applies the exact per-(face, tile) edge test (see bin_faces_kernel)
 #endif
@@ -87,6 +102,7 @@ typedef float f4v  __attribute__((ext_vector_type(4), aligned(4)));
 
 typedef float f2v  __attribute__((ext_vector_type(2), aligned(4)));
 typedef int   i4v  __attribute__((ext_vector_type(4)));
+typedef float mf4  __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f32_16x16x4_f32
 
 // Floats [BEGIN, END) of a face record -> dst[BEGIN..END) with the widest scalar loads that fit
 // (s_load_dwordx16 / x8 / x4 / x2): one wait per stage instead of one per field.
@@ -1447,7 +1463,16 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     __shared__ int s_pair[WAVES][64];
     __shared__ __attribute__((aligned(16))) PixIn   s_pix[WAVES][64];
     __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
+#if GENDR_MFMA_SUMS
+    // per-pair gradient partials, one row per pair: kColBlocks blocks of 16 components, rows 4 floats apart from a
+    // multiple of 16 and the four 16-row groups another 16 floats apart -- 16-byte row stores and the matrix
+    // operand reads below are both free of bank conflicts
+    constexpr int kColBlocks = (NG + 15) / 16;
+    constexpr int kRowStride = 16 * kColBlocks + 4;
+    __shared__ __attribute__((aligned(16))) float s_val[WAVES][64 * kRowStride + 48];
+#else
     __shared__ float s_val[WAVES][NG * 65];      // per-pair gradient partials, component-major, rows padded to 65
+#endif
 
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
@@ -1457,9 +1482,14 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
     constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` / `grad_rgba` are single planes, see RenderArgs
+#if GENDR_TIMERS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
 
     TileWalk tw;
     walk_init(tw, a, WAVES);
+    GENDR_T(0);                                   // 0: wave start-up (queue lengths)
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1493,15 +1523,23 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         }
         s_pix[wave][lane] = pi;
     }
+    GENDR_T(1);                                   // 1: tile record + the pixel's inputs parked in LDS
 
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
     int npairs = 0, nfaces = 0;
 
     auto run_batch = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
+        GENDR_T(2);                               // 2: entry list + emit since the last batch
 #if GENDR_ABLATE == 3
         npairs = 0; nfaces = 0; return;
 #endif
+        float gv_b[9], gt_b[NT];                  // this lane's partials, handed to the per-face sums below
+        bool live_b = false;
+#pragma unroll
+        for (int k = 0; k < 9; k++) gv_b[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; k++) gt_b[k] = 0.f;
         if (lane < npairs) {
             const int code = s_pair[wave][lane];
             const int slot = code >> 8;
@@ -1512,6 +1550,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             const float* rg = recs_g + (long)fn * REC;
             gather_record<kGatherW0, kGatherW1>(r, rg);
             gather_record<kGatherA0, kGatherA1>(r, rg);
+            GENDR_T(3);                           // 3: pair code, pixel inputs, first record gather landed
             const float pxp = px.xp, pyp = px.yp;
             Pair q;
             barycentrics(q, r, pxp, pyp);
@@ -1652,13 +1691,111 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                     }
                 }
             }
+            GENDR_T(4);                           // 4: the pair math (incl. the second gather)
+            live_b = live;
+#pragma unroll
+            for (int k = 0; k < 9; k++) gv_b[k] = gv[k];
+#pragma unroll
+            for (int k = 0; k < NT; k++) gt_b[k] = gt[k];
+#if !GENDR_MFMA_SUMS
             // every pair lane publishes its partials (zeros if the pair dropped out): column = pair index
 #pragma unroll
             for (int k = 0; k < 9; k++) s_val[wave][k * 65 + lane] = live ? gv[k] : 0.f;
 #pragma unroll
             for (int k = 0; k < NG - 9; k++) s_val[wave][(9 + k) * 65 + lane] = live ? gt[k] : 0.f;
+#endif
+        }
+#if GENDR_MFMA_SUMS
+        // ---- per-face sums on the matrix pipe.
+        // S[slot][comp] = sum over the batch's pairs of Ind[slot][pair] * V[pair][comp] with Ind = 1 where the pair
+        // belongs to the face in that slot: a 16 x 64 by 64 x 16 product per (16 slots, 16 components), i.e. sixteen
+        // v_mfma_f32_16x16x4_f32.  f32 in, f32 accumulate: each step is fma(1 or 0, v, acc), bit for bit a sequential
+        // f32 sum in a fixed pair order -- deterministic inside the batch like the scalar loop it replaces, but without
+        // its chain of dependent LDS round trips (the longest face of the batch used to set the trip count), and on a
+        // pipe nothing else in this kernel uses: the VALU is free for the other waves meanwhile.
+        // 0 * inf would poison the other faces' sums, so a pair with a non-finite partial (degenerate faces) zeroes its
+        // row and adds its values itself.
+        {
+            float vals[16 * kColBlocks];
+#pragma unroll
+            for (int k = 0; k < 16 * kColBlocks; k++) vals[k] = 0.f;
+            bool mine = false;
+            if (lane < npairs && live_b) {
+                float chk = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; k++) { vals[k] = gv_b[k]; chk += fabsf(gv_b[k]); }
+#pragma unroll
+                for (int k = 0; k < NG - 9; k++) { vals[9 + k] = gt_b[k]; chk += fabsf(gt_b[k]); }
+                mine = !(chk < INFINITY);
+            }
+            if (mine) {
+                const long face_lin = (long)t.b * a.nf + s_face[wave][s_pair[wave][lane] >> 8].fn;
+#pragma unroll
+                for (int k = 0; k < NG; k++) {
+                    if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, vals[k]);
+                    else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), vals[k]);
+                    vals[k] = 0.f;
+                }
+            }
+            float* row = &s_val[wave][lane * kRowStride + (lane >> 4) * 16];
+#pragma unroll
+            for (int c = 0; c < 4 * kColBlocks; c++)
+                reinterpret_cast<float4*>(row)[c] = make_float4(vals[4 * c], vals[4 * c + 1], vals[4 * c + 2], vals[4 * c + 3]);
         }
         __builtin_amdgcn_wave_barrier();
+        GENDR_T(5);                               // 5: partials to LDS
+#if GENDR_ABLATE == 4
+        npairs = 0; nfaces = 0; return;
+#endif
+        {
+            const int grp = lane >> 4, sub = lane & 15;
+            // face slots of this lane group's sixteen pairs (rows of pairs beyond npairs are zero: their slot is irrelevant)
+            int sl[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int4 c4 = reinterpret_cast<const int4*>(&s_pair[wave][16 * grp])[q];
+                sl[4 * q] = c4.x >> 8; sl[4 * q + 1] = c4.y >> 8; sl[4 * q + 2] = c4.z >> 8; sl[4 * q + 3] = c4.w >> 8;
+            }
+            const float* vbase = &s_val[wave][(16 * grp) * kRowStride + grp * 16 + sub];
+            for (int pass = 0; pass * 16 < nfaces; pass++) {
+#pragma unroll
+                for (int cb = 0; cb < kColBlocks; cb++) {
+                    // two accumulators: consecutive steps do not wait for each other's 40-cycle result
+                    mf4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                    float bv[16], iv[16];
+#pragma unroll
+                    for (int st = 0; st < 16; st++) {
+                        iv[st] = (sl[st] == sub + 16 * pass) ? 1.f : 0.f;
+                        bv[st] = vbase[st * kRowStride + cb * 16];
+                    }
+#pragma unroll
+                    for (int st = 0; st < 16; st += 2) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(iv[st], bv[st], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(iv[st + 1], bv[st + 1], acc2, 0, 0, 0);
+                    }
+                    acc += acc2;
+                    const int comp = cb * 16 + sub;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int slot = 16 * pass + 4 * grp + i;
+                        const float v = acc[i];
+#if GENDR_ABLATE == 8
+                        if (v == 12345.678f) {
+#else
+                        if (slot < nfaces && comp < NG && v != 0.f) {
+#endif
+                            const long face_lin = (long)t.b * a.nf + s_face[wave][slot].fn;
+                            if (comp < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + comp, v);
+                            else          unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (comp - 9), v);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#else
+        __builtin_amdgcn_wave_barrier();
+        GENDR_T(5);                               // 5: partials to LDS
 #if GENDR_ABLATE == 4
         npairs = 0; nfaces = 0; return;
 #endif
@@ -1686,6 +1823,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             }
         }
         __builtin_amdgcn_wave_barrier();
+#endif
+        GENDR_T(6);                               // 6: segment sums + atomics issued
         npairs = 0;
         nfaces = 0;
     };
@@ -1713,7 +1852,12 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         if (!flush) emit(m);
     });
     __builtin_amdgcn_wave_barrier();
+    GENDR_T(7);                                   // 7: tail of the tile (entry walk after the last batch)
     }   // tile loop
+#if GENDR_TIMERS
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long*>(a.control + 16 * kCtlStride + 64) + i, tacc[i]);
+#endif
 }
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
