@@ -297,10 +297,11 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     constexpr int REC = record_floats(TEXM);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // launched with one wavefront per workgroup
     if (i < ncontrol / kCtlStride) control[i * kCtlStride] = 0;                         // queue counters for this call
-    if (i >= total_faces) return;
+    if ((long)blockIdx.x * blockDim.x >= total_faces) return;                           // whole wavefront past the end
+    const bool in_range = i < total_faces;                                              // lanes past the end help with the stores
     float f[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
+    for (int k = 0; k < 9; k++) f[k] = in_range ? faces[i * 9 + k] : 0.f;
     FaceGeom g;
     face_geometry(f, g);
 
@@ -373,13 +374,15 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     // bin record: box, then (a, b, c, wcull) per edge.  The edge test is only handed over when the three coefficients are
     // finite (a tile-corner evaluation of an infinite coefficient times a zero pixel coordinate would not bound the
     // per-pixel value, which is NaN there and never rejected).
-    float4* b4 = reinterpret_cast<float4*>(boxes + i * kBinRec);
-    b4[0] = make_float4(xlo, xhi, ylo, yhi);
+    if (in_range) {
+        float4* b4 = reinterpret_cast<float4*>(boxes + i * kBinRec);
+        b4[0] = make_float4(xlo, xhi, ylo, yhi);
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float a = g.inv[3 * k], b = g.inv[3 * k + 1], c = g.inv[3 * k + 2];
-        const bool finite = fabsf(a) < INFINITY && fabsf(b) < INFINITY && fabsf(c) < INFINITY;
-        b4[1 + k] = make_float4(a, b, c, finite ? wcull[k] : -INFINITY);
+        for (int k = 0; k < 3; k++) {
+            const float a = g.inv[3 * k], b = g.inv[3 * k + 1], c = g.inv[3 * k + 2];
+            const bool finite = fabsf(a) < INFINITY && fabsf(b) < INFINITY && fabsf(c) < INFINITY;
+            b4[1 + k] = make_float4(a, b, c, finite ? wcull[k] : -INFINITY);
+        }
     }
 
     // the record leaves in 16-byte stores (REC is a multiple of 4 floats)
@@ -408,17 +411,27 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         const double rz = 1. / (double)f[3 * k + 2];
         r[kRecRZ + 2 * k] = __int_as_float(__double2loint(rz)); r[kRecRZ + 2 * k + 1] = __int_as_float(__double2hiint(rz));
     }
-    if (TEXM == kTexSurface1) {
+    if (TEXM == kTexSurface1 && in_range) {
         const long nxt = (i + 1 < total_faces) ? i + 1 : i;   // reference reads the next face's texel (:179-182); none after the last
 #pragma unroll
         for (int k = 0; k < 3; k++) { r[kRecTex + k] = textures[i * 3 + k]; r[kRecTex + 3 + k] = textures[nxt * 3 + k]; }
-    } else if (TEXM == kTexVertex) {
+    } else if (TEXM == kTexVertex && in_range) {
 #pragma unroll
         for (int k = 0; k < 9; k++) r[kRecTex + k] = textures[i * 9 + k];
     }
-    float4* out4 = reinterpret_cast<float4*>(records + i * REC);
+    // The 64 records of a wavefront are contiguous in HBM (64 * REC floats): they go through LDS so that every store
+    // instruction writes 1 KiB of consecutive bytes instead of 64 scattered 16-byte pieces 4 * REC bytes apart (the
+    // scattered form made this kernel store-bound: 15.5 us at C2).
+    __shared__ __attribute__((aligned(16))) float s_out[kThreads * REC];
+    float4* mine4 = reinterpret_cast<float4*>(s_out + (threadIdx.x & 63) * REC);
 #pragma unroll
-    for (int q = 0; q < REC / 4; q++) out4[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    for (int q = 0; q < REC / 4; q++) mine4[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    __builtin_amdgcn_wave_barrier();
+    const long first = (long)blockIdx.x * blockDim.x;                      // first face of this wavefront
+    const int nrec = (int)min((long)kThreads, total_faces - first);
+    float4* dst4 = reinterpret_cast<float4*>(records + first * REC);
+    const float4* src4 = reinterpret_cast<const float4*>(s_out);
+    for (int q = threadIdx.x & 63; q < nrec * (REC / 4); q += 64) dst4[q] = src4[q];
 }
 
 // faces_info in the reference's own layout [B*nf][27] (kernel.cu:620-676)
