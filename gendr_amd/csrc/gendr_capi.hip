@@ -105,7 +105,7 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm, bool silhouette 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t boxes_off, records_off, masks_off, lists_off, tileoff_off, tileinfo_off, entries_off, control_off, total;
+    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, control_off, total;
     int tiles_x, chunks, supers_x, ncontrol;
     long ent_cap8;
 };
@@ -124,7 +124,7 @@ long entry_capacity(long B, long tiles, long nf)
 }
 
 // workspace layout: [bin records B*nf*16 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
-//                   [tile queues B*tiles i32][tile_off B*tiles i32][tile_info B*tiles 4 x i32][entry pool][control counters]
+//                   [tile queues B*tiles i32][queue records B*tiles 4 x i32][entry pool][control counters]
 Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
 {
     Workspace w;
@@ -138,8 +138,7 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.records_off = align256((size_t)B * nf * kBinRec * sizeof(float));
     w.masks_off = w.records_off + align256((size_t)B * nf * record_floats(texm) * sizeof(float));
     w.lists_off = w.masks_off + align256(tiles * w.chunks * sizeof(unsigned long long));
-    w.tileoff_off = w.lists_off + align256(tiles * sizeof(int));
-    w.tileinfo_off = w.tileoff_off + align256(tiles * sizeof(int));
+    w.tileinfo_off = w.lists_off + align256(tiles * sizeof(int));
     w.entries_off = w.tileinfo_off + align256(tiles * sizeof(int4));
     w.control_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
     w.ncontrol = kCtlInts;
@@ -156,7 +155,6 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + w.masks_off);
     a.tile_list = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.lists_off);
     a.control = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.control_off);
-    a.tile_off = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.tileoff_off);
     a.tile_info = reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.tileinfo_off);
     a.entries = reinterpret_cast<CoverEnt*>(static_cast<char*>(const_cast<void*>(workspace)) + w.entries_off);
     a.ent_cap8 = w.ent_cap8;

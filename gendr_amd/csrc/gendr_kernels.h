@@ -216,10 +216,10 @@ struct RenderArgs {
     int*          tile_list;    // [B * tiles_per_image]: 8 queues of global tile ids, see kCtlInts
     int*          control;      // queue lengths
     CoverEnt*     entries;      // entry pool: 8 regions of ent_cap8 entries (one per tile queue)
-    int*          tile_off;     // [B * tiles_per_image]: first entry of the tile, or -1 (pool exhausted: the render
-                                //   kernels then run the per-pixel tests themselves, from the mask row)
-    int4*         tile_info;    // [B * tiles_per_image], parallel to tile_list: (tile, first entry or -1, entries, 0) of the
-                                //   queue slot, written by cover_kernel: one scalar load tells a render wave all it needs
+    int4*         tile_info;    // [B * tiles_per_image], parallel to tile_list: (tile, first entry, entries, 0) of the queue
+                                //   slot -- tile and first entry from bin_faces_kernel (-1: pool exhausted, the render
+                                //   kernels then run the per-pixel tests themselves from the mask row), the entry count
+                                //   from cover_kernel: one scalar load tells a wave all it needs
     long          ent_cap8;     // capacity of one region of the entry pool
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
@@ -658,9 +658,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
         base_e = __builtin_amdgcn_readfirstlane(base_e);
         base_n = __builtin_amdgcn_readfirstlane(base_n);
         if ((listed >> lane) & 1ull) {
-            a.tile_list[queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt)] = (int)g;
+            const long slot = queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt);
             const long at = (long)base_n + before;                              // inside region x of the pool
-            a.tile_off[g] = (at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL) ? (int)((long)x * a.ent_cap8 + at) : -1;
+            const int off = (at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL) ? (int)((long)x * a.ent_cap8 + at) : -1;
+            a.tile_list[slot] = (int)g;
+            a.tile_info[slot] = make_int4((int)g, off, 0, 0);                   // the coverage kernel fills in the entry count
         }
         if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
     }
@@ -1035,12 +1037,9 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int slot = lane >> 3, prow = lane & 7;
     for (; tw.next < tw.total; tw.next += tw.stride) {
-        const int tile = __builtin_amdgcn_readfirstlane(a.tile_list[tw.qbase + tw.next]);
-        const int off = __builtin_amdgcn_readfirstlane(a.tile_off[tile]);
-        if (off < 0) {                              // no room in the pool: the render kernels test this tile themselves
-            if (lane == 0) a.tile_info[tw.qbase + tw.next] = make_int4(tile, -1, 0, 0);
-            continue;
-        }
+        const i4v qi = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));     // (tile, first entry) from the binning kernel
+        const int tile = qi.x, off = qi.y;
+        if (off < 0) continue;                      // no room in the pool: the render kernels test this tile themselves
         TileCtx t;
         tile_setup(t, a, tile);
         const float* recs_g = a.records + (long)t.b * a.nf * REC;

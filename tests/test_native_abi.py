@@ -77,17 +77,16 @@ def test_validate_shapes(native_lib):
 
 def test_workspace_bytes(native_lib):
     p = _params(image_size=256)
-    # bin record 64 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile queue + entry offset +
-    # entry count 4 B each per tile, the entry pool (16 B per slot: 32 per tile + 64 per face, at most tiles * faces),
+    # bin record 64 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile queue 4 B and queue record 16 B per tile, the entry pool (16 B per slot: 32 per tile + 64 per face, at most tiles * faces),
     # control block (24 counters, 4 KiB apart); every part 256-byte aligned
     n = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(p))
     control = 24 * 1024 * 4
     tiles = 2 * 32 * 32
     pool = (32 * tiles + 64 * 2 * 1280) * 16
-    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + 2 * tiles * 4 + tiles * 16 + pool + control
+    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + control
     # tiny problems: the pool never exceeds one slot per (tile, face)
     small = native_lib.gendr_workspace_bytes(1, 2, 1, ctypes.byref(_params(image_size=8)))
-    assert small == 256 * 5 + 512 + 256 + control    # five sub-256-byte parts, 2 records (448 B), an 8-slot pool, the counters
+    assert small == 256 * 4 + 512 + 256 + control    # four sub-256-byte parts, 2 records (448 B), an 8-slot pool, the counters
     assert native_lib.gendr_workspace_bytes(2, 1280, 3, ctypes.byref(_params(image_size=256, texture_type='vertex'))) > n
     assert native_lib.gendr_workspace_bytes(2, 1280, 0, ctypes.byref(p)) == 0
 
