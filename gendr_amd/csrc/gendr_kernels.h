@@ -232,7 +232,24 @@ struct RenderArgs {
     double r_zrange;            // 1 / (far - near)        (kernel.cu:826)
     double r_nzrange;           // 1 / (near - far)        (kernel.cu:1026)
     double r_is;                // 1 / image_size          (kernel.cu:718-719)
+    float  gamma_k0;            // gamma family constants, see DistParams
+    double gamma_pdf_c;
 };
+
+// reciprocals of the 31 divisors of gamma's Kummer series -> LDS, once per wave (only the kernels that can meet a gamma
+// distribution carry the table)
+template <int DIST>
+__device__ __forceinline__ const double* gamma_table(double* s_tab, const RenderArgs& a)
+{
+    if constexpr (DIST == kGamma || DIST == kGammaRev || DIST == -1) {
+        const int lane = threadIdx.x & 63;
+        if (lane < kGammaSteps - 1) s_tab[lane] = 1. / (double)(a.p.dist_shape + (float)(lane + 1));
+        __builtin_amdgcn_wave_barrier();
+        return s_tab;
+    } else {
+        return nullptr;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // per-face setup
@@ -1205,7 +1222,8 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
+    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` is one plane [B,is,is], nothing else is written
@@ -1488,7 +1506,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale};
+    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);

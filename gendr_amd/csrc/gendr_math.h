@@ -41,11 +41,16 @@ struct DistParams {
     float shape;   // p of gamma
     float shift;   // shift (in units of tau) of the one-sided families
     double rscale; // RN_double(1 / (double)scale), see div_by()
+    // gamma family: what does not depend on the pair, computed once per call on the host (kernel.cu:309,:420-421)
+    float  gamma_k0;       // (float)(1. / tgamma(shape + 1.)), first Kummer term
+    double gamma_pdf_c;    // pow(1. / scale, shape) / tgamma(shape)
+    const double* gamma_r; // gamma_r[i - 1] = RN_double(1 / (double)(shape + i)), i = 1..31, or NULL: divide
 };
 
 GENDR_HD DistParams make_dist_params(float scale, float shape, float shift)
 {
-    DistParams d = {scale, shape, shift, 1. / (double)scale};
+    DistParams d = {scale, shape, shift, 1. / (double)scale,
+                    (float)(1. / tgamma((double)shape + 1.)), pow(1. / (double)scale, (double)shape) / tgamma((double)shape), nullptr};
     return d;
 }
 
@@ -208,8 +213,14 @@ template <> struct Dist<kWigner> {
 template <> struct Dist<kGaussian> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return norm_cdf(div_by(sign * x, d.rscale)); }   // :292-293
     static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :404-405 (exp in double)
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
+        // gradient side (see grad_div): the density to fp32 accuracy, exp in float instead of double
+        const float q = div_by(x, d.rscale);
+        return (float)(d.rscale * 0.3989422804014327) * expf(-0.5f * q * q);
+#else
         const double q = (double)div_by(x, d.rscale);
         return (float)(1. / (double)d.scale / sqrt(2. * kPi) * exp(-0.5 * q * q));
+#endif
     }
 };
 
@@ -302,10 +313,11 @@ template <bool REV> struct GammaFamily {                                        
         const float xs = shifted<REV>(sign, x, d);
         const float xr = div_by(xs, d.rscale);               // xs / scale, used 34 times below
         if ((double)xr > kGammaCut) return REV ? 0.f : 1.f;
-        float kummers = (float)(1. / tgamma((double)d.shape + 1.));
+        float kummers = d.gamma_k0;                          // (float)(1. / tgamma(shape + 1.))
         float factor = kummers;
         for (int i = 1; i < kGammaSteps; i++) {              // 32-term Kummer series, float
-            factor *= xr / (d.shape + i);
+            // xr / (shape + i): the 31 divisors are the same for every pair -> exact quotients by their reciprocals
+            factor *= d.gamma_r ? div_by(xr, d.gamma_r[i - 1]) : xr / (d.shape + i);
             kummers += factor;
         }
         const float y = powf(xr, d.shape) * expf(div_by(-xs, d.rscale)) * kummers;
@@ -321,8 +333,7 @@ template <bool REV> struct GammaFamily {                                        
             if (sign * x - d.shift * d.scale >= 0.f) return 0.f;
             xs = -((double)sign * (double)x - (double)d.shift * (double)d.scale);
         }
-        return (float)(pow(1. / (double)d.scale, (double)d.shape) / tgamma((double)d.shape)
-                       * pow(xs, (double)d.shape - 1.) * exp(-xs / (double)d.scale));
+        return (float)(d.gamma_pdf_c * pow(xs, (double)d.shape - 1.) * exp(-xs / (double)d.scale));
     }
 };
 template <> struct Dist<kGamma> : GammaFamily<false> {};
@@ -446,11 +457,16 @@ template <> struct TConorm<kYager> {
     static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :511-519
         if (p <= 0.f) return quiet_nan();
         const float a = 1.f - a_ex, b = 1.f - b_new;
-        const float c = (float)fmax(0., 1. - pow(pow(1. - (double)a, (double)p) + pow(1. - (double)b, (double)p), 1. / (double)p));
+        const double xa = 1. - (double)a, xb = 1. - (double)b;
+        // p = 2 (the setting of the reference's benchmark table, train_reconstruction.py:551): pow(x, 2.) is x * x and
+        // pow(s, .5) is sqrt(s) up to the last bit of a double -- two multiplies and a square root instead of three pow()
+        const float c = p == 2.f ? (float)fmax(0., 1. - sqrt(xa * xa + xb * xb))
+                                 : (float)fmax(0., 1. - pow(pow(xa, (double)p) + pow(xb, (double)p), 1. / (double)p));
         return 1.f - c;
     }
     static GENDR_HD float grad(float A, float b, float p) {                                              // :590-592
         if (A == 1.f) return 0.f;
+        if (p == 2.f) return (float)((double)b * (1. / (double)A));            // pow(b, 1.) * pow(A, -1.)
         return (float)(pow((double)b, (double)p - 1.) * pow((double)A, 1. - (double)p));
     }
 };
