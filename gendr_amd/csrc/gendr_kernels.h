@@ -1679,7 +1679,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                     // distance gradient, kernel.cu:1034-1052.  Heaviside: D' = 0 times uninitialised
                     // values in the reference -> defined as exactly 0 here (DESIGN.md quirk i).
                     if (dist != kHeaviside) {
-                        if constexpr (DIST >= 0)       C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
+                        if constexpr (DIST == kLogistic) C_xy *= div_by(q.frag * (1 - q.frag), dp.rscale);   // :378-380: y is the CDF just computed
+                        else if constexpr (DIST >= 0)  C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
                         else if constexpr (DIST == -2) C_xy *= pdf_light_rt(dist, q.sign, q.dis, dp);
                         else                           C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
                         const float tw[3] = {q.t0 + q.w0, q.t1 + q.w1, q.t2 + q.w2};
