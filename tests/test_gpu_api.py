@@ -161,3 +161,66 @@ def test_shape_optimisation_loop_through_the_alias_package(native_lib):
         loss.backward()
         opt.step()
     assert torch.isfinite(verts).all() and loss.item() < first
+
+
+def test_multiview_reconstruction_step_through_the_alias_package(native_lib):
+    """The call pattern of experiments/train_reconstruction.py:211-241,179-200: a batch of predicted meshes, duplicated
+    ([Ma, Mb, Ma, Mb]) and seen from [Va, Va, Vb, Vb] (4 x batch views), Lighting -> LookAt(viewing_angle=15) ->
+    GenDR(image_size=64, dist_eps=300, aggr_rgb_func='hard'), multiview IoU on the alpha channel, Laplacian + Flatten
+    regularisers, one optimiser step; then the evaluation path: face_vertices -> voxelization(32) -> IoU with a grid."""
+    import gendr
+    from gendr_amd.synthetic import icosphere
+    from oracle import iou_ref
+    v, f = icosphere(2)
+    Bm = 4                                                       # meshes per half batch; 4 * 2 * Bm = 32 rendered views
+    base = torch.from_numpy(v).cuda()
+    faces1 = torch.from_numpy(f).int().cuda()
+    offs = torch.nn.Parameter(torch.zeros(2 * Bm, v.shape[0], 3, device='cuda'))
+    scale = torch.linspace(0.5, 0.8, 2 * Bm, device='cuda')[:, None, None]
+    transform = gendr.LookAt(viewing_angle=15)
+    lighting = gendr.Lighting()
+    renderer = gendr.GenDR(image_size=64, dist_func='uniform', dist_scale=10 ** -1.5, dist_squared=False, dist_shape=0,
+                           dist_shift=0, dist_eps=300., aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=0,
+                           aggr_rgb_func='hard')
+    lap = gendr.LaplacianLoss(base, faces1.long(), average=True).cuda()      # the script moves the whole Model to the GPU
+    flat = gendr.FlattenLoss(faces1.long(), average=True).cuda()
+    va = gendr.functional.get_points_from_angles(torch.full((Bm,), 2.732), torch.full((Bm,), 30.0), torch.arange(Bm) * -15.0).cuda()
+    vb = gendr.functional.get_points_from_angles(torch.full((Bm,), 2.732), torch.full((Bm,), 30.0), torch.arange(Bm) * -15.0 - 90.0).cuda()
+    with torch.no_grad():                                        # targets: the unit-scale sphere from the same views
+        tm = gendr.Mesh(base[None].repeat(4 * Bm, 1, 1) * 0.9, faces1[None].repeat(4 * Bm, 1, 1))
+        transform.set_eyes(torch.cat((va, va, vb, vb), 0))
+        targets = renderer(transform(lighting(tm))).chunk(4, dim=0)
+    opt = torch.optim.Adam([offs], lr=1e-2)
+    losses = []
+    for _ in range(6):
+        vertices = base[None] * scale + offs                     # [2 Bm, nv, 3] = [Ma, Mb]
+        faces = faces1[None].repeat(2 * Bm, 1, 1)
+        laplacian_loss, flatten_loss = lap(vertices), flat(vertices)
+        transform.set_eyes(torch.cat((va, va, vb, vb), 0))
+        mesh = gendr.Mesh(torch.cat((vertices, vertices), 0), torch.cat((faces, faces), 0))
+        sil = renderer(transform(lighting(mesh))).chunk(4, dim=0)
+        assert sil[0].shape == (Bm, 4, 64, 64)
+
+        def iou_loss(p, t):
+            dims = (1, 2)
+            return 1 - ((p * t).sum(dims) / ((p + t - p * t).sum(dims) + 1e-6)).sum() / p.shape[0]
+        loss = (iou_loss(sil[0][:, 3], targets[0][:, 3]) + iou_loss(sil[1][:, 3], targets[0][:, 3]) +
+                iou_loss(sil[2][:, 3], targets[2][:, 3]) + iou_loss(sil[3][:, 3], targets[2][:, 3])) / 4
+        want = iou_ref.multiview_iou_loss([s.detach().cpu().numpy() for s in sil], targets[0].cpu().numpy(), targets[2].cpu().numpy())
+        assert abs(float(loss.detach()) - want) < 1e-5
+        total = loss + 5e-3 * laplacian_loss + 5e-4 * flatten_loss
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert torch.isfinite(offs).all() and losses[-1] < losses[0]
+    # evaluation path (train_reconstruction.py:233-241)
+    with torch.no_grad():
+        vertices = base[None] * scale + offs
+        faces_ = gendr.functional.face_vertices(vertices, faces1[None].repeat(2 * Bm, 1, 1)).data
+        faces_norm = faces_ * 1. * (32. - 1) / 32. + 0.5
+        vox = gendr.functional.voxelization(faces_norm, 32, False).cpu().numpy()
+        vox = vox.transpose(0, 2, 1, 3)[:, :, :, ::-1]
+        assert vox.shape == (2 * Bm, 32, 32, 32) and 0 < vox.sum() < vox.size
+        iou = (vox * vox).sum((1, 2, 3)) / (0 < (vox + vox)).sum((1, 2, 3))
+        assert np.allclose(iou, 1.0)
