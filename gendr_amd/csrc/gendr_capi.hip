@@ -104,6 +104,8 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm, bool silhouette 
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+extern "C" float gendr_cull_radius(const gendr_params* p);
+
 struct Workspace {
     size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, control_off, total;
     int tiles_x, chunks, supers_x, ncontrol;
@@ -111,16 +113,27 @@ struct Workspace {
 };
 
 // Entry pool (CoverEnt, 16 bytes each): every listed (tile, face) gets a slot, so the worst case is tiles * nf.  Sized
-// for 32 listings per tile plus 64 per face -- several times what the configs of BASELINE.json list (C2 5.7 per tile,
-// C4 31 per tile / 100 per face, C5 144 per face) -- and never more than the worst case; a tile that finds the pool
-// exhausted is still rendered exactly (tile_off = -1: the render kernels apply the per-pixel tests themselves).
-long entry_capacity(long B, long tiles, long nf)
+// for 32 listings per tile plus, per face, the tiles a face of a few pixels reaches with the option set's cull radius
+// (at least 64) -- C2 lists 5.7 per tile and 4.6 per face, C4 (37-pixel radius) 45 per tile and 145 per face, C5 144 per
+// face -- doubled for fewer than 8 batch items (the 8 regions of the pool are then bands of an image, and the bands
+// under the object hold most of the listings), never more than the worst case.  A tile that finds the pool exhausted is
+// still rendered exactly (first entry = -1: the render kernels apply the per-pixel tests themselves), only slower.
+long entry_capacity(long B, long tiles, long nf, const gendr_params* p)
 {
     const long worst = B * tiles * nf;
-    long want = 32 * B * tiles + 64 * B * nf;
-    if (want > worst) want = worst;
-    if (want > 0x7fffff00L) want = 0x7fffff00L;          // entry offsets are ints
-    return (want + 7) / 8 * 8;
+    const float r = gendr_cull_radius(p);                        // NDC units; +inf: no radius
+    double per_face = 64.;
+    if (r == r && r < 1e30f) {
+        const double reach = 2. * (double)r * p->image_size / 2. / kTile + 3.;   // tiles across: 2 r in pixels / 8, plus the face
+        per_face = fmax(per_face, 2. * reach * reach);
+    } else {
+        per_face = (double)tiles;
+    }
+    double want = 32. * (double)B * tiles + per_face * (double)B * nf;
+    if (B < 8) want *= 2.;
+    if (want > (double)worst) want = (double)worst;
+    if (want > (double)0x7fffff00L) want = (double)0x7fffff00L;   // entry offsets are ints
+    return ((long)want + 7) / 8 * 8;
 }
 
 // workspace layout: [bin records B*nf*16 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
@@ -133,7 +146,7 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.chunks = (nf + 63) / 64;
     w.supers_x = (w.tiles_x + 7) / 8;
     const size_t tiles = (size_t)B * w.tiles_x * w.tiles_x;
-    w.ent_cap8 = entry_capacity(B, (long)w.tiles_x * w.tiles_x, nf) / 8;
+    w.ent_cap8 = entry_capacity(B, (long)w.tiles_x * w.tiles_x, nf, p) / 8;
     w.boxes_off = 0;
     w.records_off = align256((size_t)B * nf * kBinRec * sizeof(float));
     w.masks_off = w.records_off + align256((size_t)B * nf * record_floats(texm) * sizeof(float));

@@ -82,7 +82,7 @@ def test_workspace_bytes(native_lib):
     n = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(p))
     control = 24 * 1024 * 4
     tiles = 2 * 32 * 32
-    pool = (32 * tiles + 64 * 2 * 1280) * 16
+    pool = 2 * (32 * tiles + 64 * 2 * 1280) * 16          # radius of 1.3 pixels: 64 per face; fewer than 8 batch items: doubled
     assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + control
     # tiny problems: the pool never exceeds one slot per (tile, face)
     small = native_lib.gendr_workspace_bytes(1, 2, 1, ctypes.byref(_params(image_size=8)))
