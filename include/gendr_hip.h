@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GENDR_ABI_VERSION 2
+#define GENDR_ABI_VERSION 3
 
 enum {
     GENDR_OK              = 0,
@@ -64,8 +64,10 @@ typedef struct gendr_params {
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward
- * reads: per-face cull boxes and records (this build's replacement for `faces_info`) plus the
- * per-tile face masks of the exact culling.  0 on invalid arguments. */
+ * reads: per-face bin records and face records (this build's replacement for `faces_info`), the
+ * per-tile face masks, tile queues and queue records of the exact culling, and the pool of per-tile
+ * coverage entries (face, pixel mask) both render kernels walk.  Depends on the option set (the pool
+ * grows with the cull radius).  0 on invalid arguments. */
 unsigned long long gendr_workspace_bytes(int B, int nf, int T, const gendr_params* p);
 
 /* Validates the option set exactly as the reference's asserts / device checks do. */
