@@ -73,6 +73,10 @@
                                // (one or two accumulators alike), so the scalar LDS loop stays the default.
 #endif
 
+#ifndef GENDR_SUM_LANES
+#define GENDR_SUM_LANES 1      // lanes per (face, component) segment in the backward sums: 1 or 4
+#endif
+
 #ifndef GENDR_TIMERS
 #define GENDR_TIMERS 0         // 1: the backward kernel accumulates its wave-time per phase (diagnostic build, tools/phase_timers.py)
 #endif
@@ -1831,6 +1835,35 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 #if GENDR_ABLATE == 4
         npairs = 0; nfaces = 0; return;
 #endif
+#if GENDR_SUM_LANES == 4
+        // The pairs of one face are contiguous.  Four lanes per (face, component): each sums every fourth value of the
+        // segment (the four read neighbouring addresses), a two-step quad reduction combines them and the first lane
+        // issues one hardware fp32 atomic -- deterministic inside the batch, no LDS atomics, and a quarter of the
+        // dependent LDS round trips of one lane per segment (the longest face of the batch sets the trip count).
+        for (int e = lane; e < nfaces * NG * 4; e += 64) {
+            const int sub = e & 3, item = e >> 2;
+            const int slot = item / NG, k = item - slot * NG;
+            const FaceEnt fe = s_face[wave][slot];
+            const int cnt = __popcll(fe.mask);
+            const float* col = &s_val[wave][k * 65 + fe.base];
+            float v0 = 0.f, v1 = 0.f;
+            int i = sub;
+            for (; i + 4 < cnt; i += 8) { v0 += col[i]; v1 += col[i + 4]; }
+            if (i < cnt) v0 += col[i];
+            float v = v0 + v1;
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+#if GENDR_ABLATE == 8
+            if (v == 12345.678f) {
+#else
+            if (sub == 0 && v != 0.f) {
+#endif
+                const long face_lin = (long)t.b * a.nf + fe.fn;
+                if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
+                else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
+            }
+        }
+#else
         // The pairs of one face are contiguous.  One lane per (face, component) sums its segment in pair order and
         // issues one hardware fp32 atomic: deterministic inside the batch, no LDS atomics.
         for (int e = lane; e < nfaces * NG; e += 64) {
@@ -1854,6 +1887,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                 else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
             }
         }
+#endif
         __builtin_amdgcn_wave_barrier();
 #endif
         GENDR_T(6);                               // 6: segment sums + atomics issued
