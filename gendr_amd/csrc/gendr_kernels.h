@@ -947,10 +947,11 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 //
 // Measured on the headline scene: a face touches only ~14 of a tile's 64 pixels, so evaluating "one face per
 // loop iteration, lane = pixel" leaves ~78 % of the lanes idle in the expensive stages.  Instead:
-//   phase A  (cheap): box test, barycentrics, edge reject for every pixel of the tile against every listed face --
-//            forward: lane = pixel, one face per iteration (collect_pairs); backward: lane = (face, pixel row), eight
-//            faces per step (for_each_face_mask).  The surviving (pixel, face) pairs are appended -- in ascending
-//            (face, pixel) order -- to a wavefront-private list in LDS, together with the face's ballot mask;
+//   coverage (cheap, once per forward call, cover_kernel): box test, barycentrics, edge reject for every pixel of the
+//            tile against every listed face, lane = (face, pixel row), eight faces per step -> per tile the entries
+//            (face, pixel mask) in ascending face order;
+//   walk     the render kernels append the (pixel, face) pairs of the entries -- in ascending (face, pixel) order --
+//            to a wavefront-private list in LDS, together with the face's mask;
 //   phase B  (lane = pair, dense): every lane fetches ITS pair's face record from L2 and runs the distance,
 //            CDF, clip/depth and colour stages; results go back to LDS;
 //   phase C  forward : lane = pixel again; each pixel folds the results of its own pairs in list order, i.e. in
@@ -988,7 +989,8 @@ constexpr int kGatherW0 = 1, kGatherW1 = 4;      // floats [4, 16): inv, flag wo
 constexpr int kGatherA0 = 5, kGatherA1 = 11;     // floats [20, 44)
 constexpr int kGatherB0 = 10;                    // floats [40, REC)
 
-// phase A for one listed face; returns the ballot of surviving lanes (0 = nothing to do)
+// the exact per-pixel tests for one listed face, lane = pixel (used when a tile has no slice of the entry pool);
+// returns the ballot of surviving lanes (0 = nothing to do)
 template <int REC>
 __device__ __forceinline__ unsigned long long collect_pairs(const TileCtx& t, RecPtr rp, Pair& q)
 {
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
 // body(0, 0, true) once (the caller flushes its open batch there) -- from ONE call site, so that the caller's phase B
 // is compiled once (two sites doubled the kernels' code).  64 entries arrive by one coalesced 16-byte load per lane; v_readlane hands them to the
 // (wave-uniform) body one by one.
-// A tile without a slice of the entry pool (tile_off < 0) produces its entries here instead, up to 64 at a time: its
+// A tile without a slice of the entry pool (off < 0) produces its entries here instead, up to 64 at a time: its
 // mask row is walked with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact
 // per-pixel tests (collect_pairs) -- same entries, only slower.
 template <int REC, typename Body>
