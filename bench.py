@@ -333,7 +333,7 @@ def measure(args, wl, dist, dev):
                 wl.fv.grad = None
                 wl.tex.grad = None
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # RCCL's watchdog thread may query events meanwhile
                     wl.step()
                 for _ in range(2):
                     graph.replay()

@@ -42,6 +42,7 @@ control = w[control_off:].view(np.int32)
 nlisted = [int(control[x * 1024]) for x in range(8)]
 listings = int(sum(bin(int(m)).count('1') for m in masks)) if masks.size < 4e6 else -1
 n_entries = n_pairs = n_batches = fallback = 0
+per_tile = []
 for x in range(8):
     qb = x * tiles // 8
     for s in range(nlisted[x]):
@@ -54,8 +55,15 @@ for x in range(8):
         n_entries += cnt
         n_pairs += int(pc.sum())
         n_batches += int(np.ceil(pc.sum() / 64.0))
+        per_tile.append((int(pc.sum()), int(cnt), x, s))
 P = isz * isz
 print('%s batch %d: %d tiles, %d listed (%.1f %%), %s listings (bin), %d entries (cover) = %.1f per listed tile, %d pairs = %.1f per entry, '
       '%.2f pairs per pixel, >= %d batches (%.1f per listed tile), %d tiles without a pool slice'
       % (args.config, Bn, tiles, sum(nlisted), 100.0 * sum(nlisted) / tiles, listings, n_entries, n_entries / max(1, sum(nlisted)),
          n_pairs, n_pairs / max(1, n_entries), n_pairs / float(Bn * P), n_batches, n_batches / max(1, sum(nlisted)), fallback))
+pt = np.array([t[0] for t in per_tile]); en = np.array([t[1] for t in per_tile])
+q = [0, 10, 25, 50, 75, 90, 99, 100]
+print('pairs per listed tile, percentiles', q, ':', [int(v) for v in np.percentile(pt, q)], ' mean %.0f' % pt.mean())
+print('entries per listed tile, percentiles', q, ':', [int(v) for v in np.percentile(en, q)], ' mean %.0f' % en.mean())
+print('share of all pairs in the heaviest 1 %% / 10 %% of tiles: %.1f %% / %.1f %%'
+      % (100.0 * np.sort(pt)[-max(1, len(pt) // 100):].sum() / pt.sum(), 100.0 * np.sort(pt)[-max(1, len(pt) // 10):].sum() / pt.sum()))
