@@ -1591,6 +1591,15 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             const float pxp = px.xp, pyp = px.yp;
             Pair q;
             barycentrics(q, r, pxp, pyp);
+#ifdef GENDR_PAD_VALU
+            {   // diagnostic: GENDR_PAD_VALU extra independent VALU instructions per batch (how VALU-bound is the kernel?)
+                int p0 = lane, p1 = lane, p2 = lane, p3 = lane;
+#pragma unroll
+                for (int i = 0; i < GENDR_PAD_VALU / 4; i++)
+                    asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                if (p0 + p1 + p2 + p3 == 0x7fffffff) q.w0 = 0.f;
+            }
+#endif
 
             float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
             float gt[NT];                      // texture partials

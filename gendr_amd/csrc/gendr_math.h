@@ -320,11 +320,30 @@ template <bool REV> struct GammaFamily {                                        
             factor *= d.gamma_r ? div_by(xr, d.gamma_r[i - 1]) : xr / (d.shape + i);
             kummers += factor;
         }
-        const float y = powf(xr, d.shape) * expf(div_by(-xs, d.rscale)) * kummers;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // shape 1 and 2 (2: the setting of BASELINE config 5): the power is the operand resp. one multiply -- the
+        // correctly rounded value, which the library's powf (~100 instructions) reaches to within an ulp
+        const float xp = d.shape == 2.f ? xr * xr : (d.shape == 1.f ? xr : powf(xr, d.shape));
+#else
+        const float xp = powf(xr, d.shape);
+#endif
+        const float y = xp * expf(div_by(-xs, d.rscale)) * kummers;
         return REV ? 1.f - y : y;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // explicit double in the reference
         if (d.shape < 0.f) return quiet_nan();
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
+        // gradient side (see grad_div): shape 1 and 2 (2: BASELINE config 5) need no power -- xs^(shape - 1) is 1 resp.
+        // xs -- and the density to fp32 accuracy only a float exponential, instead of ~400 double-precision
+        // instructions per pair.  Other shapes keep the double evaluation (a float power would underflow where the
+        // constant in front is large).
+        if (d.shape == 2.f || d.shape == 1.f) {
+            if (!REV) { if (sign * x + d.shift * d.scale <= 0.f) return 0.f; }
+            else      { if (sign * x - d.shift * d.scale >= 0.f) return 0.f; }
+            const float xf = shifted<REV>(sign, x, d);
+            return (float)d.gamma_pdf_c * (d.shape == 2.f ? xf : 1.f) * expf(div_by(-xf, d.rscale));
+        }
+#endif
         double xs;
         if (!REV) {
             if (sign * x + d.shift * d.scale <= 0.f) return 0.f;

@@ -84,6 +84,9 @@ OPTION_MATRIX = [
     ("exp_prob", dict(dist_func='exponential', dist_scale=3e-2, dist_shift=0.5)),
     ("exprev_prob", dict(dist_func='exponential_rev', dist_scale=2e-2)),
     ("gammarev_prob", dict(dist_func='gamma_rev', dist_shape=1.5, dist_scale=2e-2)),
+    ("gamma1_shift_prob", dict(dist_func='gamma', dist_shape=1.0, dist_shift=0.5, dist_scale=2e-2)),       # shape 1 and 2: the device's
+    ("gammarev2_einstein", dict(dist_func='gamma_rev', dist_shape=2.0, dist_scale=2e-2, aggr_alpha_func='einstein')),   # power-free branches
+    ("gamma35_prob", dict(dist_func='gamma', dist_shape=3.5, dist_scale=1e-2)),
     ("levy_prob", dict(dist_func='levy', dist_scale=2e-2, dist_shift=1.0)),
     ("levyrev_prob", dict(dist_func='levy_rev', dist_scale=1e-2)),
     ("uniform_hardalpha", dict(aggr_alpha_func='hard')),
