@@ -40,7 +40,12 @@ cap = (control_off - off) // 16
 ent = w[off:off + cap * 16].view(np.uint32).reshape(cap, 4)
 control = w[control_off:].view(np.int32)
 nlisted = [int(control[x * 1024]) for x in range(8)]
-listings = int(sum(bin(int(m)).count('1') for m in masks)) if masks.size < 4e6 else -1
+listings = 0                                              # mask rows of listed tiles only: the others are never written
+for x in range(8):
+    qb = x * tiles // 8
+    for s_ in range(nlisted[x]):
+        row = masks[int(info[qb + s_][0]) * chunks:(int(info[qb + s_][0]) + 1) * chunks]
+        listings += int(sum(bin(int(m)).count('1') for m in row))
 n_entries = n_pairs = n_batches = fallback = 0
 per_tile = []
 for x in range(8):
