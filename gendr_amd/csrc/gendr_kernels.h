@@ -668,6 +668,19 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
     const long g = tile_base + (long)ty_l * tiles_x + tx_l;
     const int xq = tile_ok ? queue_of_tile(g, a.total_tiles) : -1;
     if (!tile_ok) listed_faces = 0;
+    // A super-tile that lies wholly inside the image and lists nothing anywhere becomes ONE entry of the unlisted
+    // queue, -(its first tile) - 1: the forward kernel fills its 64 x 64 pixels with 256-byte row segments instead of
+    // 64 tiles' 32-byte ones (image rows of a multiple of four pixels, for 16-byte stores).
+    if ((is & 3) == 0 && sx * 64 + 64 <= is && sy * 64 + 64 <= is) {
+        const int x0 = __builtin_amdgcn_readlane(xq, 0);
+        if (__ballot(listed_faces == 0 && xq == x0) == ~0ull) {
+            if (lane == 0) {
+                const int base_e = atomicAdd(a.control + (8 + x0) * kCtlStride, 1);
+                a.tile_list[queue_begin(x0 + 1, a.total_tiles) - 1 - base_e] = -(int)g - 1;
+            }
+            return;
+        }
+    }
     unsigned long long todo = __ballot(tile_ok);
     while (todo) {
         const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
@@ -1248,11 +1261,11 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     // Tiles no face is listed for: what the loop below leaves for an untouched pixel (kernel.cu:728-740, :845-861).
     // First, so that these stores (two thirds of the output planes in the headline scene) drain while the wave computes.
 #if GENDR_ABLATE != 5
-    for (int r = tw.rank; r < tw.empties; r += tw.stride) {
+    auto fill_tile = [&](int tile) __attribute__((always_inline)) {
         TileCtx t;
-        tile_setup(t, a, __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]));
-        if (!t.valid) continue;
-        if constexpr (kSil) { a.rgba[(long)t.b * P + t.pix] = 0.f; continue; }
+        tile_setup(t, a, tile);
+        if (!t.valid) return;
+        if constexpr (kSil) { a.rgba[(long)t.b * P + t.pix] = 0.f; return; }
         float* out = a.rgba + (long)t.b * 4 * P + t.pix;
         float* aux = a.aux + (long)t.b * 2 * P + t.pix;
         out[3 * P] = 0.f;
@@ -1272,6 +1285,38 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             aux[0] = a.softmax_sum0;
             aux[P] = a.p.aggr_rgb_eps;
         }
+    };
+    // 64 x 64 pixels of one plane from `first` (16-byte aligned): lane = (row & 3, 4 pixels), sixteen 1-KiB stores
+    auto fill_plane = [&](float* first, float v) __attribute__((always_inline)) {
+        const int lane = threadIdx.x & 63;
+        float4* p4 = reinterpret_cast<float4*>(first + (long)(lane >> 4) * a.is + (lane & 15) * 4);
+        const float4 v4 = make_float4(v, v, v, v);
+#pragma unroll
+        for (int it = 0; it < 16; it++) p4[(long)it * a.is] = v4;           // 4 rows further = is float4s further
+    };
+    const bool wide_ok = !a.p.background_from_buffer && ((reinterpret_cast<unsigned long long>(a.rgba) | (kSil ? 0ull : reinterpret_cast<unsigned long long>(a.aux))) & 15ull) == 0ull;
+    for (int r = tw.rank; r < tw.empties; r += tw.stride) {
+        const int tile = __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]);
+        if (tile >= 0) { fill_tile(tile); continue; }
+        // an empty super-tile (see bin_faces_kernel): tiles g0 + 8 rows of 8
+        const int g0 = -tile - 1;
+        if (!wide_ok) {
+            for (int k = 0; k < 64; k++) fill_tile(g0 + (k >> 3) * a.tiles_x + (k & 7));
+            continue;
+        }
+        const int b = g0 / a.tiles_per_image;
+        const int tl = g0 - b * a.tiles_per_image;
+        const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
+        const long at = (long)ty * 8 * a.is + tx * 8;
+        if constexpr (kSil) { fill_plane(a.rgba + (long)b * P + at, 0.f); continue; }
+        float* out = a.rgba + (long)b * 4 * P + at;
+        float* aux = a.aux + (long)b * 2 * P + at;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            fill_plane(out + k * P, rgb_soft ? (a.p.background[k] * a.softmax_sum0) / a.softmax_sum0 : a.p.background[k]);
+        fill_plane(out + 3 * P, 0.f);
+        fill_plane(aux, rgb_soft ? a.softmax_sum0 : 10000000.f);
+        fill_plane(aux + P, rgb_soft ? a.p.aggr_rgb_eps : -1.f);
     }
 #endif
 
