@@ -1297,11 +1297,11 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const bool wide_ok = !a.p.background_from_buffer && ((reinterpret_cast<unsigned long long>(a.rgba) | (kSil ? 0ull : reinterpret_cast<unsigned long long>(a.aux))) & 15ull) == 0ull;
     for (int r = tw.rank; r < tw.empties; r += tw.stride) {
         const int tile = __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]);
-        if (tile >= 0) { fill_tile(tile); continue; }
-        // an empty super-tile (see bin_faces_kernel): tiles g0 + 8 rows of 8
-        const int g0 = -tile - 1;
-        if (!wide_ok) {
-            for (int k = 0; k < 64; k++) fill_tile(g0 + (k >> 3) * a.tiles_x + (k & 7));
+        // a negative entry is an empty super-tile (see bin_faces_kernel): tiles g0 + 8 rows of 8
+        const int g0 = tile < 0 ? -tile - 1 : tile;
+        if (tile >= 0 || !wide_ok) {
+            const int n = tile < 0 ? 64 : 1;
+            for (int k = 0; k < n; k++) fill_tile(g0 + (k >> 3) * a.tiles_x + (k & 7));
             continue;
         }
         const int b = g0 / a.tiles_per_image;
