@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--config', default='c2')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--modes', default='normal,offscreen(scan only),nocull')
     args = ap.parse_args()
     cfg = B.CONFIGS[args.config]
     Bn = args.batch or cfg['batch']
@@ -47,6 +48,8 @@ def main():
     res = {}
     for name, shift, cull in (('normal', 0.0, 1), ('offscreen(scan only)', 10.0, 1), ('nocull', 0.0, 0)):
         if name == 'nocull' and args.config not in ('c2', 'c3'):
+            continue
+        if name not in args.modes.split(','):
             continue
         p = parity.hip_params(isz, o, dict(extra, cull=cull))
         f = fv.clone(); f[..., 0] += shift
