@@ -497,6 +497,15 @@ int gendr_backward_f64(const double* faces, const double* textures, const double
     return check_launch();
 }
 
+#if GENDR_TRACE
+// diagnostic builds only: copies the wave trace of the last backward launch to the host (n_waves x 8 x u64)
+int gendr_trace_read(unsigned long long* dst, int n_waves)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return GENDR_E_LAUNCH;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), (size_t)n_waves * 8 * sizeof(unsigned long long)) == hipSuccess ? GENDR_OK : GENDR_E_LAUNCH;
+}
+#endif
+
 int gendr_selftest(int what, unsigned long long* report16, void* stream)
 {
     if (!report16) return GENDR_E_NULL;

@@ -77,6 +77,17 @@
 #define GENDR_SUM_LANES 1      // lanes per (face, component) segment in the backward sums: 1 or 4
 #endif
 
+#ifndef GENDR_TRACE
+#define GENDR_TRACE 0          // 1: every wave of the backward kernel leaves time stamps (diagnostic build, tools/wave_trace.py)
+#endif
+#if GENDR_TRACE
+// per wave: start, queue lengths known, pixel inputs parked, first batch entered, end (shader clock of its CU), batches,
+// start and end on the chip-wide 100 MHz clock (s_memrealtime)
+__device__ unsigned long long g_wave_trace[1 << 17][8];
+#define GENDR_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); tr[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GENDR_STAMP(i) do {} while (0)
+#endif
 #ifndef GENDR_TIMERS
 #define GENDR_TIMERS 0         // 1: the backward kernel accumulates its wave-time per phase (diagnostic build, tools/phase_timers.py)
 #endif
@@ -1577,9 +1588,15 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     unsigned long long tlast = __builtin_readcyclecounter();
 #endif
 
+#if GENDR_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tr[0] = __builtin_readcyclecounter();
+    tr[6] = __builtin_amdgcn_s_memrealtime();
+#endif
     TileWalk tw;
     walk_init(tw, a, WAVES);
     GENDR_T(0);                                   // 0: wave start-up (queue lengths)
+    GENDR_STAMP(1);
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1614,6 +1631,9 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         s_pix[wave][lane] = pi;
     }
     GENDR_T(1);                                   // 1: tile record + the pixel's inputs parked in LDS
+#if GENDR_TRACE
+    if (!tr[2]) GENDR_STAMP(2);
+#endif
 
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
     int npairs = 0, nfaces = 0;
@@ -1621,6 +1641,10 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     auto run_batch = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
         GENDR_T(2);                               // 2: entry list + emit since the last batch
+#if GENDR_TRACE
+        if (!tr[3]) GENDR_STAMP(3);
+        tr[5] += 1;
+#endif
 #if GENDR_ABLATE == 3
         npairs = 0; nfaces = 0; return;
 #endif
@@ -1987,6 +2011,15 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 #if GENDR_TIMERS
     if ((threadIdx.x & 63) == 0)
         for (int i = 0; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long*>(a.control + 16 * kCtlStride + 64) + i, tacc[i]);
+#endif
+#if GENDR_TRACE
+    GENDR_STAMP(4);
+    tr[7] = __builtin_amdgcn_s_memrealtime();
+    {
+        const unsigned w = (unsigned)blockIdx.x * WAVES + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && w < (1u << 17))
+            for (int i = 0; i < 8; i++) g_wave_trace[w][i] = tr[i];
+    }
 #endif
 }
 
