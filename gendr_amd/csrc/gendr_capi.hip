@@ -570,6 +570,10 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     if (texm == kTexSurface1)    hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurface1)>, dim3(cblocks), dim3(kThreads), 0, s, a);
     else if (texm == kTexVertex) hipLaunchKernelGGL(cover_kernel<record_floats(kTexVertex)>, dim3(cblocks), dim3(kThreads), 0, s, a);
     else                         hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurfaceN)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+    e = check_launch();
+    if (e != GENDR_OK) return e;
+    // heavy tiles first: the render kernels' waves take the queue slots in the order this leaves in tile_list
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderThreads), 0, s, a);
     return check_launch();
 }
 

@@ -737,7 +737,7 @@ struct TileCtx {
 // The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
 // own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
 // tiles list a face) that is one tile per wave and no wave is launched in vain.
-struct TileWalk { long qbase, qend; int total, empties, rank, next, stride; };
+struct TileWalk { long qbase, qend; int total, empties, rank, next, stride, ordered; };
 
 __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int waves_per_block)
 {
@@ -746,9 +746,17 @@ __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int 
     w.qend = queue_begin(xcd + 1, a.total_tiles);
     w.total = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride]);
     w.empties = __builtin_amdgcn_readfirstlane(a.control[(8 + xcd) * kCtlStride]);
+    w.ordered = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride + 16]);     // kCtlOrdered, see order_tiles_kernel
     w.stride = (int)(gridDim.x >> 3) * waves_per_block;
     w.rank = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * waves_per_block + (int)(threadIdx.x >> 6));
     w.next = w.rank;
+}
+
+// the queue record the wave takes next: slot `next`, or, in a queue ordered heavy-first, the slot listed there
+__device__ __forceinline__ i4v walk_record(const TileWalk& w, const RenderArgs& a)
+{
+    const int slot = w.ordered ? __builtin_amdgcn_readfirstlane(a.tile_list[w.qbase + w.next]) : w.next;
+    return *(const GENDR_CONST_AS i4v*)(a.tile_info + (w.qbase + slot));
 }
 
 __device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int tile)
@@ -1104,6 +1112,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
         const float yp_a = pixel_coord(a.is - 1 - row_a, a.is, a.r_is);
         CoverEnt* out = a.entries + off;
         int nout = 0;
+        int my_pairs = 0;                          // pixels this lane's (face, row) slots found: summed into the tile's weight
 
         int word0 = 0, group0 = 0;                 // next 64-word group to load / base word of the loaded one
         unsigned long long wv = 0ull, nz = 0ull;   // this lane's word of the loaded group / its non-zero words still to unpack
@@ -1150,6 +1159,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                         m8 |= (live ? 1u : 0u) << c;
                     }
                 }
+                my_pairs += __popc(m8);
                 const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
                 const unsigned hi = (unsigned)__shfl_down((int)v, 4);                  // lane 8s reads lane 8s+4 (rows 4-7)
                 const bool owns = prow == 0 && (v | hi) != 0u;
@@ -1163,8 +1173,52 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) a.tile_info[tw.qbase + tw.next] = make_int4(tile, off, nout, 0);
+        // the tile's (pixel, face) pairs = its weight for order_tiles_kernel
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) my_pairs += __shfl_xor(my_pairs, d);
+        if (lane == 0) a.tile_info[tw.qbase + tw.next] = make_int4(tile, off, nout, my_pairs);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// heavy tiles first
+// ---------------------------------------------------------------------------------------------
+// Workgroups are dispatched in index order and wave r of a queue takes slot r, so the tiles a launch starts last are
+// the ones the binning kernel happened to append last -- and the launch ends when the longest of them does.  Measured on
+// the headline scene (tools/wave_trace.py): the last waves of the backward kernel start at 80-88 us and run 40-48 us
+// (10-12 batches), so a third of the 129 us passes with the chip emptying.  This kernel (one workgroup per queue) sorts
+// the queue's slots by descending weight class (the pairs the coverage kernel counted, in steps of 32) into the
+// front of tile_list, which nothing reads once the queue records exist; the render kernels then take slot
+// tile_list[r]: the heavy tiles start first and the tail is made of one-batch tiles (C2: backward kernel 124 -> 107 us,
+// forward 108 -> 92 us; C3 +18 % frames/s).  Queues longer than kOrderMax keep the binning order: with dozens of tiles
+// per wave slot the tail does not matter, and neighbouring tiles running together share their records and output lines
+// in the L2 (C5, 55 k tiles per queue at batch 32: 3.5 % slower when ordered).
+constexpr int kOrderThreads = 1024, kOrderClasses = 32, kOrderMax = 1 << 14;
+constexpr int kCtlOrdered = 16;        // control[x * kCtlStride + kCtlOrdered] != 0: queue x is ordered
+
+__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const RenderArgs a)
+{
+    __shared__ int s_count[kOrderClasses], s_cursor[kOrderClasses];
+    const int x = blockIdx.x;
+    const long qbase = queue_begin(x, a.total_tiles);
+    const int n = a.control[x * kCtlStride];
+    if (n > kOrderMax || n < 2) {
+        if (threadIdx.x == 0) a.control[x * kCtlStride + kCtlOrdered] = 0;
+        return;
+    }
+    if (threadIdx.x < kOrderClasses) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kOrderThreads)
+        atomicAdd(&s_count[min(a.tile_info[qbase + i].w >> 5, kOrderClasses - 1)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int c = kOrderClasses - 1; c >= 0; c--) { s_cursor[c] = at; at += s_count[c]; }
+        a.control[x * kCtlStride + kCtlOrdered] = 1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kOrderThreads)
+        a.tile_list[qbase + atomicAdd(&s_cursor[min(a.tile_info[qbase + i].w >> 5, kOrderClasses - 1)], 1)] = i;
 }
 
 // Walks a tile's coverage entries in ascending face order and calls body(fn, mask, false) for each, then
@@ -1334,7 +1388,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries): scalar load
+    const i4v ti = walk_record(tw, a);          // (tile, first entry, entries, pairs): scalar loads
     TileCtx t;
     tile_setup(t, a, ti.x);
 
@@ -1600,7 +1654,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries): scalar load
+    const i4v ti = walk_record(tw, a);          // (tile, first entry, entries, pairs): scalar loads
     TileCtx t;
     tile_setup(t, a, ti.x);
     {

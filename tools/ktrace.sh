@@ -10,7 +10,7 @@ for f in "$@"; do
   echo "== $f"
   python - "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv,sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:6]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:8]:
     print('  %-62s calls %5s avg %8.1f us  min %8.1f' % (r['Name'][:62], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3))
 PY
 done
