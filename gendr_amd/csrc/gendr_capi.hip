@@ -107,7 +107,8 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" float gendr_cull_radius(const gendr_params* p);
 
 struct Workspace {
-    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, control_off, total;
+    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, sorted_off, control_off, total;
+    bool ordered;              // the render kernels walk the heavy-first copy of the queue records (order_tiles_kernel)
     int tiles_x, chunks, supers_x, ncontrol;
     long ent_cap8;
 };
@@ -137,7 +138,8 @@ long entry_capacity(long B, long tiles, long nf, const gendr_params* p)
 }
 
 // workspace layout: [bin records B*nf*16 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
-//                   [tile queues B*tiles i32][queue records B*tiles 4 x i32][entry pool][control counters]
+//                   [tile queues B*tiles i32][queue records B*tiles 4 x i32][entry pool]
+//                   [heavy-first copy of the queue records, up to kOrderTilesMax tiles][control counters]
 Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
 {
     Workspace w;
@@ -153,7 +155,9 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.lists_off = w.masks_off + align256(tiles * w.chunks * sizeof(unsigned long long));
     w.tileinfo_off = w.lists_off + align256(tiles * sizeof(int));
     w.entries_off = w.tileinfo_off + align256(tiles * sizeof(int4));
-    w.control_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
+    w.sorted_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
+    w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16;
+    w.control_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
     w.ncontrol = kCtlInts;
     w.total = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
     return w;
@@ -168,7 +172,8 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + w.masks_off);
     a.tile_list = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.lists_off);
     a.control = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.control_off);
-    a.tile_info = reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.tileinfo_off);
+    a.tile_info_raw = reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.tileinfo_off);
+    a.tile_info = w.ordered ? reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.sorted_off) : a.tile_info_raw;
     a.entries = reinterpret_cast<CoverEnt*>(static_cast<char*>(const_cast<void*>(workspace)) + w.entries_off);
     a.ent_cap8 = w.ent_cap8;
     a.textures = textures;
@@ -504,6 +509,12 @@ int gendr_trace_read(unsigned long long* dst, int n_waves)
     if (hipDeviceSynchronize() != hipSuccess) return GENDR_E_LAUNCH;
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), (size_t)n_waves * 8 * sizeof(unsigned long long)) == hipSuccess ? GENDR_OK : GENDR_E_LAUNCH;
 }
+int gendr_span_read(unsigned long long* dst, int kernel, int n)
+{
+    if (hipDeviceSynchronize() != hipSuccess || kernel < 0 || kernel > 2) return GENDR_E_LAUNCH;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_span_trace), (size_t)n * 2 * sizeof(unsigned long long),
+                               (size_t)kernel * (1 << 16) * 2 * sizeof(unsigned long long)) == hipSuccess ? GENDR_OK : GENDR_E_LAUNCH;
+}
 #endif
 
 int gendr_selftest(int what, unsigned long long* report16, void* stream)
@@ -572,9 +583,12 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     else                         hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurfaceN)>, dim3(cblocks), dim3(kThreads), 0, s, a);
     e = check_launch();
     if (e != GENDR_OK) return e;
-    // heavy tiles first: the render kernels' waves take the queue slots in the order this leaves in tile_list
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderThreads), 0, s, a);
-    return check_launch();
+    // heavy tiles first: the render kernels walk the sorted copy of the queue records
+    if (w.ordered) {
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderThreads), 0, s, a);
+        return check_launch();
+    }
+    return GENDR_OK;
 }
 
 int gendr_forward(const float* faces, const float* textures, float* rgba, float* aggrs_info,

@@ -85,8 +85,16 @@
 // start and end on the chip-wide 100 MHz clock (s_memrealtime)
 __device__ unsigned long long g_wave_trace[1 << 17][8];
 #define GENDR_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); tr[i] = __builtin_readcyclecounter(); } while (0)
+// start and end (chip-wide clock) of every wave of the coverage (0) and forward (2) kernels and of every workgroup of the
+// binning kernel (1)
+__device__ unsigned long long g_span_trace[3][1 << 16][2];
+#define GENDR_SPAN_BEGIN const unsigned long long span0_ = __builtin_amdgcn_s_memrealtime()
+#define GENDR_SPAN_END(k, idx) do { __builtin_amdgcn_s_waitcnt(0); \
+        if ((threadIdx.x & 63) == 0 && (unsigned)(idx) < (1u << 16)) { g_span_trace[k][idx][0] = span0_; g_span_trace[k][idx][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define GENDR_STAMP(i) do {} while (0)
+#define GENDR_SPAN_BEGIN do {} while (0)
+#define GENDR_SPAN_END(k, idx) do {} while (0)
 #endif
 #ifndef GENDR_TIMERS
 #define GENDR_TIMERS 0         // 1: the backward kernel accumulates its wave-time per phase (diagnostic build, tools/phase_timers.py)
@@ -231,7 +239,9 @@ struct RenderArgs {
     int*          tile_list;    // [B * tiles_per_image]: 8 queues of global tile ids, see kCtlInts
     int*          control;      // queue lengths
     CoverEnt*     entries;      // entry pool: 8 regions of ent_cap8 entries (one per tile queue)
-    int4*         tile_info;    // [B * tiles_per_image], parallel to tile_list: (tile, first entry, entries, 0) of the queue
+    int4*         tile_info_raw;// the queue records in the order the binning kernel appended them (written by it and cover_kernel)
+    int4*         tile_info;    // what the render kernels walk: the heavy-first copy of order_tiles_kernel, or tile_info_raw
+                                // [B * tiles_per_image], parallel to tile_list: (tile, first entry, entries, pairs) of the queue
                                 //   slot -- tile and first entry from bin_faces_kernel (-1: pool exhausted, the render
                                 //   kernels then run the per-pixel tests themselves from the mask row), the entry count
                                 //   from cover_kernel: one scalar load tells a wave all it needs
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
 {
     __shared__ unsigned long long s_words[64][kBinGroup + 1];
     __shared__ int s_listed[64];
+    GENDR_SPAN_BEGIN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int is = a.is, tiles_x = a.tiles_x, chunks = a.chunks;
@@ -689,6 +700,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
                 const int base_e = atomicAdd(a.control + (8 + x0) * kCtlStride, 1);
                 a.tile_list[queue_begin(x0 + 1, a.total_tiles) - 1 - base_e] = -(int)g - 1;
             }
+            GENDR_SPAN_END(1, blockIdx.x);
             return;
         }
     }
@@ -715,10 +727,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __r
             const long at = (long)base_n + before;                              // inside region x of the pool
             const int off = (at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL) ? (int)((long)x * a.ent_cap8 + at) : -1;
             a.tile_list[slot] = (int)g;
-            a.tile_info[slot] = make_int4((int)g, off, 0, 0);                   // the coverage kernel fills in the entry count
+            a.tile_info_raw[slot] = make_int4((int)g, off, 0, 0);               // the coverage kernel fills in the entry count
         }
         if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
     }
+    GENDR_SPAN_END(1, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -737,7 +750,7 @@ struct TileCtx {
 // The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
 // own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
 // tiles list a face) that is one tile per wave and no wave is launched in vain.
-struct TileWalk { long qbase, qend; int total, empties, rank, next, stride, ordered; };
+struct TileWalk { long qbase, qend; int total, empties, rank, next, stride; };
 
 __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int waves_per_block)
 {
@@ -746,17 +759,9 @@ __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int 
     w.qend = queue_begin(xcd + 1, a.total_tiles);
     w.total = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride]);
     w.empties = __builtin_amdgcn_readfirstlane(a.control[(8 + xcd) * kCtlStride]);
-    w.ordered = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride + 16]);     // kCtlOrdered, see order_tiles_kernel
     w.stride = (int)(gridDim.x >> 3) * waves_per_block;
     w.rank = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * waves_per_block + (int)(threadIdx.x >> 6));
     w.next = w.rank;
-}
-
-// the queue record the wave takes next: slot `next`, or, in a queue ordered heavy-first, the slot listed there
-__device__ __forceinline__ i4v walk_record(const TileWalk& w, const RenderArgs& a)
-{
-    const int slot = w.ordered ? __builtin_amdgcn_readfirstlane(a.tile_list[w.qbase + w.next]) : w.next;
-    return *(const GENDR_CONST_AS i4v*)(a.tile_info + (w.qbase + slot));
 }
 
 __device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int tile)
@@ -1094,13 +1099,14 @@ template <int REC>
 __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
 {
     __shared__ int s_flist[kListCap];
+    GENDR_SPAN_BEGIN;
     TileWalk tw;
     walk_init(tw, a, 1);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int slot = lane >> 3, prow = lane & 7;
     for (; tw.next < tw.total; tw.next += tw.stride) {
-        const i4v qi = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));     // (tile, first entry) from the binning kernel
+        const i4v qi = *(const GENDR_CONST_AS i4v*)(a.tile_info_raw + (tw.qbase + tw.next)); // (tile, first entry) from the binning kernel
         const int tile = qi.x, off = qi.y;
         if (off < 0) continue;                      // no room in the pool: the render kernels test this tile themselves
         TileCtx t;
@@ -1173,11 +1179,19 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
             }
             __builtin_amdgcn_wave_barrier();
         }
-        // the tile's (pixel, face) pairs = its weight for order_tiles_kernel
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) my_pairs += __shfl_xor(my_pairs, d);
-        if (lane == 0) a.tile_info[tw.qbase + tw.next] = make_int4(tile, off, nout, my_pairs);
+        // the tile's (pixel, face) pairs = its weight for order_tiles_kernel: summed across the lanes into lane 63 (an
+        // inclusive scan inside each row of 16 lanes, then the two DPP row broadcasts: six VALU steps, no LDS)
+#define GENDR_DPP_IADD(v, ctrl, rows) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xF, false))
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x111, 0xF);      // row_shr:1
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x112, 0xF);      // row_shr:2
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x114, 0xF);      // row_shr:4
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x118, 0xF);      // row_shr:8
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
+#undef GENDR_DPP_IADD
+        if (lane == 63) a.tile_info_raw[tw.qbase + tw.next] = make_int4(tile, off, nout, my_pairs);
     }
+    GENDR_SPAN_END(0, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1186,15 +1200,15 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
 // Workgroups are dispatched in index order and wave r of a queue takes slot r, so the tiles a launch starts last are
 // the ones the binning kernel happened to append last -- and the launch ends when the longest of them does.  Measured on
 // the headline scene (tools/wave_trace.py): the last waves of the backward kernel start at 80-88 us and run 40-48 us
-// (10-12 batches), so a third of the 129 us passes with the chip emptying.  This kernel (one workgroup per queue) sorts
-// the queue's slots by descending weight class (the pairs the coverage kernel counted, in steps of 32) into the
-// front of tile_list, which nothing reads once the queue records exist; the render kernels then take slot
-// tile_list[r]: the heavy tiles start first and the tail is made of one-batch tiles (C2: backward kernel 124 -> 107 us,
-// forward 108 -> 92 us; C3 +18 % frames/s).  Queues longer than kOrderMax keep the binning order: with dozens of tiles
-// per wave slot the tail does not matter, and neighbouring tiles running together share their records and output lines
-// in the L2 (C5, 55 k tiles per queue at batch 32: 3.5 % slower when ordered).
-constexpr int kOrderThreads = 1024, kOrderClasses = 32, kOrderMax = 1 << 14;
-constexpr int kCtlOrdered = 16;        // control[x * kCtlStride + kCtlOrdered] != 0: queue x is ordered
+// (10-12 batches), so a third of the 129 us passes with the chip emptying.  This kernel (one workgroup per queue) copies
+// the queue's records into a second array sorted by descending weight class (the pairs the coverage kernel counted, in
+// steps of 32) and the render kernels walk that copy: the heavy tiles start first and the tail is made of one-batch
+// tiles (C2: backward kernel 124 -> 107 us, forward 108 -> 92 us; C3 +18 % frames/s).  Launched only for up to
+// kOrderTilesMax tiles in all (the host decides; RenderArgs::tile_info then points at the copy): with dozens of tiles per
+// wave slot the tail does not matter, and neighbouring tiles running together share their records and output lines in the
+// L2 (C5, 2.1 M tiles at batch 32: 3.5 % slower when ordered).
+constexpr int kOrderThreads = 1024, kOrderClasses = 32;
+constexpr long kOrderTilesMax = 1L << 19;
 
 __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const RenderArgs a)
 {
@@ -1202,23 +1216,20 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
     const int x = blockIdx.x;
     const long qbase = queue_begin(x, a.total_tiles);
     const int n = a.control[x * kCtlStride];
-    if (n > kOrderMax || n < 2) {
-        if (threadIdx.x == 0) a.control[x * kCtlStride + kCtlOrdered] = 0;
-        return;
-    }
     if (threadIdx.x < kOrderClasses) s_count[threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kOrderThreads)
-        atomicAdd(&s_count[min(a.tile_info[qbase + i].w >> 5, kOrderClasses - 1)], 1);
+        atomicAdd(&s_count[min(a.tile_info_raw[qbase + i].w >> 5, kOrderClasses - 1)], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int at = 0;
         for (int c = kOrderClasses - 1; c >= 0; c--) { s_cursor[c] = at; at += s_count[c]; }
-        a.control[x * kCtlStride + kCtlOrdered] = 1;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kOrderThreads)
-        a.tile_list[qbase + atomicAdd(&s_cursor[min(a.tile_info[qbase + i].w >> 5, kOrderClasses - 1)], 1)] = i;
+    for (int i = threadIdx.x; i < n; i += kOrderThreads) {
+        const int4 rec = a.tile_info_raw[qbase + i];
+        a.tile_info[qbase + atomicAdd(&s_cursor[min(rec.w >> 5, kOrderClasses - 1)], 1)] = rec;
+    }
 }
 
 // Walks a tile's coverage entries in ascending face order and calls body(fn, mask, false) for each, then
@@ -1319,6 +1330,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` is one plane [B,is,is], nothing else is written
+    GENDR_SPAN_BEGIN;
 
     TileWalk tw;
     walk_init(tw, a, WAVES);
@@ -1388,7 +1400,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = walk_record(tw, a);          // (tile, first entry, entries, pairs): scalar loads
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries, pairs): scalar load
     TileCtx t;
     tile_setup(t, a, ti.x);
 
@@ -1564,7 +1576,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     }
     __builtin_amdgcn_wave_barrier();
     }   // tile loop
-
+    GENDR_SPAN_END(2, blockIdx.x * WAVES + wave);
 }
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
@@ -1654,7 +1666,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     for (; tw.next < tw.total; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = walk_record(tw, a);          // (tile, first entry, entries, pairs): scalar loads
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries, pairs): scalar load
     TileCtx t;
     tile_setup(t, a, ti.x);
     {

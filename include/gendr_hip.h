@@ -65,9 +65,10 @@ typedef struct gendr_params {
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward
  * reads: per-face bin records and face records (this build's replacement for `faces_info`), the
- * per-tile face masks, tile queues and queue records of the exact culling, and the pool of per-tile
- * coverage entries (face, pixel mask) both render kernels walk.  Depends on the option set (the pool
- * grows with the cull radius).  0 on invalid arguments. */
+ * per-tile face masks, tile queues and queue records of the exact culling, the pool of per-tile
+ * coverage entries (face, pixel mask) both render kernels walk, and (up to 2^19 tiles) the copy of the
+ * queue records sorted heaviest tile first.  Depends on the option set (the pool grows with the cull
+ * radius).  0 on invalid arguments. */
 unsigned long long gendr_workspace_bytes(int B, int nf, int T, const gendr_params* p);
 
 /* Validates the option set exactly as the reference's asserts / device checks do. */

@@ -78,12 +78,16 @@ def test_validate_shapes(native_lib):
 def test_workspace_bytes(native_lib):
     p = _params(image_size=256)
     # bin record 64 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile queue 4 B and queue record 16 B per tile, the entry pool (16 B per slot: 32 per tile + 64 per face, at most tiles * faces),
-    # control block (24 counters, 4 KiB apart); every part 256-byte aligned
+    # the heavy-first copy of the queue records (16 B per tile, for 16 .. 2^19 tiles), control block (24 counters, 4 KiB apart); every part 256-byte aligned
     n = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(p))
     control = 24 * 1024 * 4
     tiles = 2 * 32 * 32
     pool = 2 * (32 * tiles + 64 * 2 * 1280) * 16          # radius of 1.3 pixels: 64 per face; fewer than 8 batch items: doubled
-    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + control
+    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + tiles * 16 + control
+    # above 2^19 tiles the render kernels walk the queue records in the binning order: no copy
+    big = native_lib.gendr_workspace_bytes(32, 1280, 1, ctypes.byref(_params(image_size=2048)))
+    big_tiles = 32 * 256 * 256
+    assert big < 32 * 1280 * (64 + 224) + big_tiles * (20 * 8 + 4 + 16) + 16 * (32 * big_tiles + 20000 * 32 * 1280) + control + 8 * 256
     # tiny problems: the pool never exceeds one slot per (tile, face)
     small = native_lib.gendr_workspace_bytes(1, 2, 1, ctypes.byref(_params(image_size=8)))
     assert small == 256 * 4 + 512 + 256 + control    # four sub-256-byte parts, 2 records (448 B), an 8-slot pool, the counters

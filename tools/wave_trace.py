@@ -75,3 +75,21 @@ for i in np.argsort(end)[-5:]:
 edges = np.arange(0, end.max() + 5, 5.0)
 print('  waves alive per 5-us bin (all / with a tile):',
       ' '.join('%d/%d' % (int(((start < e + 5) & (end > e)).sum()), int(((start < e + 5) & (end > e) & busy).sum())) for e in edges[:-1]))
+
+# ---- start / end spans of the other kernels of the same step (coverage: per wave, binning: per workgroup, forward: per wave)
+L.gendr_span_read.restype = ctypes.c_int
+L.gendr_span_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+supers = Bn * ((isz + 63) // 64) ** 2
+for k, name, n in ((1, 'bin_faces_kernel (workgroups)', min(supers, 1 << 16)), (0, 'cover_kernel (waves)', min(nw, 1 << 16)),
+                   (2, 'render_forward_kernel (waves)', min(nw, 1 << 16))):
+    sp = np.zeros((n, 2), np.uint64)
+    assert L.gendr_span_read(sp.ctypes.data, k, n) == 0
+    sp = sp.astype(np.float64)
+    ok = sp[:, 1] > 0
+    st = (sp[ok, 0] - sp[ok, 0].min()) / 100.0
+    en = (sp[ok, 1] - sp[ok, 0].min()) / 100.0
+    print('%s: %d traced, first start -> last end %.1f us' % (name, int(ok.sum()), en.max()))
+    pr('  start', st, ident)
+    pr('  lifetime', en - st, ident)
+    edges = np.arange(0, en.max() + 5, 5.0)
+    print('    alive per 5-us bin:', ' '.join(str(int(((st < e + 5) & (en > e)).sum())) for e in edges[:-1]))
