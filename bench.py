@@ -214,8 +214,9 @@ def parse_args(argv=None):
                     help='strong: the global batch is fixed and sharded (headline); weak: the config\'s batch per GPU')
     ap.add_argument('--launch', default='auto', choices=('auto', 'eager', 'graph'),
                     help='graph: the step is captured once in a HIP graph and replayed (configs without a collective); '
-                         'auto: graph when a rank holds fewer than 32 frames (the step is then shorter than the host\'s '
-                         'launch work: batch 8 eager 0.25 ms, replayed 0.14 ms), eager otherwise')
+                         'auto: graph when a rank holds at most 32 frames (the step is then about as short as the host\'s '
+                         'launch work, 0.18-0.24 ms per step depending on the box: batch 8 eager 0.25 ms, replayed '
+                         '0.13 ms), eager otherwise')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo with --stub)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the second (weak-scaling) measurement at N > 1')
@@ -316,7 +317,7 @@ def measure(args, wl, dist, dev):
         import gendr_amd.dist as gdist
         launch = args.launch
         if launch == 'auto':
-            launch = 'graph' if wl.B < 32 else 'eager'
+            launch = 'graph' if wl.B <= 32 else 'eager'
         if launch == 'graph' and wl.cfg.get('gather'):
             launch = 'eager'                          # a collective inside the step: not captured
         graph = None
