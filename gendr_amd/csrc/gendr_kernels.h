@@ -1744,19 +1744,20 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             }
 #endif
 
+            // Two stages one after the other, not nested: `live` is narrowed by the first and guards the second, and the
+            // partials are defined in the second only (as values that survive a nest of early exits they were
+            // re-initialised at every level of it: 58 moves per batch; the empty asm below keeps the compiler from turning
+            // the final select back into such a default).
             float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
             float gt[NT];                      // texture partials
-#pragma unroll
-            for (int k = 0; k < 9; k++) gv[k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < NT; k++) gt[k] = 0.f;
+            float C_xy = 0.f, zp = 0.f;
+            float wc[3];
             bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp);
             if (live) {
                 // alpha only, and this face's depth cannot fail the near / far test (see face_setup_kernel): no depth stage
                 const bool need_depth = !(kSil && (__float_as_int(r[kRecBits]) & kBitDepthSafe));
                 if (need_depth) gather_record<kGatherB0, REC / 4>(r, rg);
                 // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
-                float C_xy = 0.f;
                 float C_alpha = px.g[3];
                 if (alpha_func != kAlphaHard) {
                     if constexpr ((ALPHA == kProbabilistic || ALPHA == kEinstein) && !GENDR_EXACT_GRADIENT)
@@ -1767,13 +1768,17 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                 }
                 C_xy += C_alpha;
 
-                float wc[3];
-                float zp = 0.f;
                 if (need_depth) {
                     zp = clip_and_depth(q, r, wc);
                     live = !(zp < a.p.near_ || zp > a.p.far_);                  // :994 drops the whole pair
                 }
+            }
+            {
                 if (live) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) gv[k] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NT; k++) gt[k] = 0.f;
                     const bool front = (__float_as_int(r[kRecBits]) & kBitFront) != 0;
                     if constexpr (kSil) {
                         // no colour term: C_xy stays the alpha partial
@@ -1889,6 +1894,10 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             for (int k = 0; k < NT; k++) gt_b[k] = gt[k];
 #if !GENDR_MFMA_SUMS
             // every pair lane publishes its partials (zeros if the pair dropped out): column = pair index
+#pragma unroll
+            for (int k = 0; k < 9; k++) asm("" : "+v"(gv[k]));
+#pragma unroll
+            for (int k = 0; k < NG - 9; k++) asm("" : "+v"(gt[k]));
 #pragma unroll
             for (int k = 0; k < 9; k++) s_val[wave][k * 65 + lane] = live ? gv[k] : 0.f;
 #pragma unroll
