@@ -77,6 +77,9 @@
 #define GENDR_SUM_LANES 1      // lanes per (face, component) segment in the backward sums: 1 or 4
 #endif
 
+#ifndef GENDR_COVER_REVERSE
+#define GENDR_COVER_REVERSE 1
+#endif
 #ifndef GENDR_TRACE
 #define GENDR_TRACE 0          // 1: every wave of the backward kernel leaves time stamps (diagnostic build, tools/wave_trace.py)
 #endif
@@ -1106,7 +1109,10 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int slot = lane >> 3, prow = lane & 7;
     for (; tw.next < tw.total; tw.next += tw.stride) {
-        const i4v qi = *(const GENDR_CONST_AS i4v*)(a.tile_info_raw + (tw.qbase + tw.next)); // (tile, first entry) from the binning kernel
+        // The queue was appended to as the binning workgroups finished: the super-tiles under the object, with the most
+        // faces to examine here, came last.  The waves take the slots from the back so that those start first.
+        const int slot_c = GENDR_COVER_REVERSE ? tw.total - 1 - tw.next : tw.next;
+        const i4v qi = *(const GENDR_CONST_AS i4v*)(a.tile_info_raw + (tw.qbase + slot_c)); // (tile, first entry) from the binning kernel
         const int tile = qi.x, off = qi.y;
         if (off < 0) continue;                      // no room in the pool: the render kernels test this tile themselves
         TileCtx t;
@@ -1189,7 +1195,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
         my_pairs = GENDR_DPP_IADD(my_pairs, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
         my_pairs = GENDR_DPP_IADD(my_pairs, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
 #undef GENDR_DPP_IADD
-        if (lane == 63) a.tile_info_raw[tw.qbase + tw.next] = make_int4(tile, off, nout, my_pairs);
+        if (lane == 63) a.tile_info_raw[tw.qbase + slot_c] = make_int4(tile, off, nout, my_pairs);
     }
     GENDR_SPAN_END(0, blockIdx.x);
 }
