@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GendrParams(ctypes.Structure):
@@ -37,6 +37,8 @@ class GendrParams(ctypes.Structure):
         ("background_from_buffer", ctypes.c_int),
         ("texel_mode", ctypes.c_int),
         ("cull", ctypes.c_int),
+        ("clear_ptr", ctypes.c_void_p),
+        ("clear_floats", ctypes.c_ulonglong),
     ]
 
 

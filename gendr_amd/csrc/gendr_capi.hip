@@ -556,13 +556,16 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     // one wavefront per workgroup: 81920 faces are only 1280 wavefronts, spread them over all CUs
     const int blocks = total > 0 ? (int)((total + 63) / 64) : 1;                        // also zeroes the control block
     const float sthr = sqrtf(p->dist_eps * p->dist_scale);       // sqrt(threshold), kernel.cu:725,747
+    if (p->clear_ptr && ((reinterpret_cast<unsigned long long>(p->clear_ptr) & 15ull) || (p->clear_floats & 3ull))) return GENDR_E_SHAPE;
+    float4* clear4 = p->clear_ptr && total > 0 ? static_cast<float4*>(p->clear_ptr) : nullptr;
+    const long clear_quads = clear4 ? (long)(p->clear_floats / 4) : 0;
     const float cull_r = gendr_cull_radius(p);
     if (texm == kTexSurface1)
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, clear4, clear_quads);
     else if (texm == kTexVertex)
-        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_);
+        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, clear4, clear_quads);
     else
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, clear4, clear_quads);
     int e = check_launch();
     if (e != GENDR_OK) return e;
     // one workgroup per (image, 64x64 super-tile): tile masks and the tile queues

@@ -337,11 +337,19 @@ template <int TEXM>
 __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const float* __restrict__ faces, const float* __restrict__ textures,
     float* __restrict__ boxes, float* __restrict__ records,
-    long total_faces, float sthr, float cull_r, int* __restrict__ control, int ncontrol, float near_, float far_)
+    long total_faces, float sthr, float cull_r, int* __restrict__ control, int ncontrol, float near_, float far_,
+    float4* __restrict__ clear4, long clear_quads)
 {
     constexpr int REC = record_floats(TEXM);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // launched with one wavefront per workgroup
     if (i < ncontrol / kCtlStride) control[i * kCtlStride] = 0;                         // queue counters for this call
+    // the caller's buffer to clear (gendr_params::clear_ptr: the gradients of the coming backward call): every workgroup
+    // zero-fills its slice with 16-byte stores while its loads are in flight
+    if (clear_quads > 0) {
+        const long per = (clear_quads + gridDim.x - 1) / gridDim.x;
+        const long q0 = (long)blockIdx.x * per, q1 = min(q0 + per, clear_quads);
+        for (long q = q0 + threadIdx.x; q < q1; q += blockDim.x) clear4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if ((long)blockIdx.x * blockDim.x >= total_faces) return;                           // whole wavefront past the end
     const bool in_range = i < total_faces;                                              // lanes past the end help with the stores
     float f[9];

@@ -159,6 +159,16 @@ def native_forward(faces, textures, params, rgba=None, aggrs_info=None):
     return rgba, aggrs_info, records
 
 
+def gradient_buffers(faces, textures, fill=True):
+    """(flat, grad_faces [B,nf,9], grad_textures like textures): one allocation (and at most one fill) for both."""
+    B, nf = faces.shape[0], faces.shape[1]
+    n_f, n_t = B * nf * 9, textures.numel()
+    n_f_pad = (n_f + 63) // 64 * 64                        # keeps grad_textures 256-byte aligned
+    n = (n_f_pad + n_t + 3) // 4 * 4                       # whole 16-byte stores for the fused clear
+    flat = (torch.zeros if fill else torch.empty)(n, dtype=faces.dtype, device=faces.device)
+    return flat, flat[:n_f].view(B, nf, 9), flat[n_f_pad:n_f_pad + n_t].view(textures.shape)
+
+
 def native_backward(faces, textures, rgba, aggrs_info, records, grad_rgba, params, grad_faces=None, grad_textures=None):
     L = _native.lib()
     B, nf = faces.shape[0], faces.shape[1]
@@ -168,11 +178,7 @@ def native_backward(faces, textures, rgba, aggrs_info, records, grad_rgba, param
     f64 = dt == torch.float64
     if grad_faces is None and grad_textures is None:
         # one zero fill for both gradients (they are small: one launch instead of two)
-        n_f, n_t = B * nf * 9, textures.numel()
-        n_f_pad = (n_f + 63) // 64 * 64                    # keep grad_textures 256-byte aligned
-        flat = torch.zeros(n_f_pad + n_t, dtype=dt, device=dev)
-        grad_faces = flat[:n_f].view(B, nf, 9)
-        grad_textures = flat[n_f_pad:].view(textures.shape)
+        _, grad_faces, grad_textures = gradient_buffers(faces, textures)
     if grad_faces is None:
         grad_faces = torch.zeros((B, nf, 9), dtype=dt, device=dev)
     if grad_textures is None:
@@ -237,7 +243,19 @@ class GenDRFunction(Function):
             raise ValueError('textures must be [B, nf, T, 3] matching face_vertices [B, nf, 3, 3]; got %s and %s'
                              % (tuple(textures.shape), tuple(face_vertices.shape)))
 
+        # The gradients of the coming backward call are allocated now and zero-filled by the per-face setup kernel on its
+        # way (gendr_params.clear_ptr): one launch less per step.  Used once; a second backward through the same graph
+        # (retain_graph) allocates and fills its own.
+        ctx.grad_buffers = None
+        if compute == torch.float32 and B * nf > 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) \
+                and os.environ.get('GENDR_FUSED_CLEAR', '1') != '0':
+            flat, gf, gt = gradient_buffers(faces, tex, fill=False)
+            params.clear_ptr = flat.data_ptr()
+            params.clear_floats = flat.numel()
+            ctx.grad_buffers = (flat, gf, gt)
         soft_colors, aggrs_info, records = native_forward(faces, tex, params)
+        params.clear_ptr = None
+        params.clear_floats = 0
         ctx.save_for_backward(faces, tex, soft_colors, records, aggrs_info)
         return soft_colors
 
@@ -246,7 +264,12 @@ class GenDRFunction(Function):
     def backward(ctx, grad_soft_colors):
         faces, tex, soft_colors, records, aggrs_info = ctx.saved_tensors
         grad = grad_soft_colors.to(ctx.compute_dtype).contiguous()
-        grad_faces, grad_textures = native_backward(faces, tex, soft_colors, aggrs_info, records, grad, ctx.params)
+        bufs, ctx.grad_buffers = ctx.grad_buffers, None
+        if bufs is not None and bufs[0].device == grad.device:
+            grad_faces, grad_textures = native_backward(faces, tex, soft_colors, aggrs_info, records, grad, ctx.params,
+                                                        grad_faces=bufs[1], grad_textures=bufs[2])
+        else:
+            grad_faces, grad_textures = native_backward(faces, tex, soft_colors, aggrs_info, records, grad, ctx.params)
         grad_faces = grad_faces.reshape(ctx.fv_shape).to(ctx.fv_dtype)
         grad_textures = grad_textures.reshape(ctx.tex_shape).to(ctx.tex_dtype)
         return (grad_faces, grad_textures) + (None,) * 17

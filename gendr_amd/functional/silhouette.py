@@ -24,12 +24,20 @@ def _params(image_size, dist_func, dist_scale, dist_squared, dist_shape, dist_sh
                        aggr_alpha_func, aggr_alpha_t_conorm_p, 'softmax', 1e-3, 1e-3, near, far, True, 'surface')
 
 
-def _forward(face_vertices, params, target=None):
+def _forward(face_vertices, params, target=None, want_grad=False):
+    """Returns (faces, alpha, workspace, target, sums, grad_faces): grad_faces is the buffer of the coming backward call,
+    zero-filled by the setup kernel of this one (gendr_params.clear_ptr), or None."""
     L = _native.lib()
     _require_device(face_vertices, 'face_vertices')
     B, nf = face_vertices.shape[:2]
     faces = face_vertices.detach().reshape(B, nf, 9).to(torch.float32).contiguous()
     dev = faces.device
+    grad_faces = None
+    if want_grad and B * nf > 0:
+        n = (B * nf * 9 + 3) // 4 * 4
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        params.clear_ptr, params.clear_floats = flat.data_ptr(), n
+        grad_faces = flat[:B * nf * 9].view(B, nf, 9)
     isz = params.image_size
     alpha = torch.empty((B, isz, isz), dtype=torch.float32, device=dev)
     ws = torch.empty((max(int(L.gendr_silhouette_workspace_bytes(B, nf, ctypes.byref(params))), 256),), dtype=torch.uint8, device=dev)
@@ -43,13 +51,15 @@ def _forward(face_vertices, params, target=None):
         check(L.gendr_silhouette_forward(_ptr(faces), _ptr(alpha), _ptr(ws), _ptr(target) if target is not None else None,
                                          _ptr(sums) if sums is not None else None, B, nf, ctypes.byref(params), _stream_ptr()),
               'gendr_silhouette_forward')
-    return faces, alpha, ws, target, sums
+    params.clear_ptr, params.clear_floats = None, 0
+    return faces, alpha, ws, target, sums, grad_faces
 
 
-def _backward(faces, alpha, ws, params, grad_alpha=None, target=None, grad_iou=None):
+def _backward(faces, alpha, ws, params, grad_alpha=None, target=None, grad_iou=None, grad_faces=None):
     L = _native.lib()
     B, nf = faces.shape[:2]
-    grad_faces = torch.zeros((B, nf, 9), dtype=torch.float32, device=faces.device)
+    if grad_faces is None:
+        grad_faces = torch.zeros((B, nf, 9), dtype=torch.float32, device=faces.device)
     with torch.cuda.device(faces.device):
         check(L.gendr_silhouette_backward(_ptr(alpha), _ptr(ws), _ptr(grad_alpha) if grad_alpha is not None else None,
                                           _ptr(target) if target is not None else None,
@@ -64,7 +74,7 @@ class SilhouetteFunction(Function):
 
     @staticmethod
     def forward(ctx, face_vertices, params):
-        faces, alpha, ws, _, _ = _forward(face_vertices, params)
+        faces, alpha, ws, _, _, ctx.grad_faces = _forward(face_vertices, params, want_grad=ctx.needs_input_grad[0])
         ctx.params, ctx.shape, ctx.dtype = params, face_vertices.shape, face_vertices.dtype
         ctx.save_for_backward(faces, alpha, ws)
         return alpha
@@ -73,7 +83,8 @@ class SilhouetteFunction(Function):
     @once_differentiable
     def backward(ctx, grad_alpha):
         faces, alpha, ws = ctx.saved_tensors
-        g = _backward(faces, alpha, ws, ctx.params, grad_alpha=grad_alpha.to(torch.float32).contiguous())
+        buf, ctx.grad_faces = ctx.grad_faces, None              # cleared by the forward call; good for one use
+        g = _backward(faces, alpha, ws, ctx.params, grad_alpha=grad_alpha.to(torch.float32).contiguous(), grad_faces=buf)
         return g.reshape(ctx.shape).to(ctx.dtype), None
 
 
@@ -83,7 +94,7 @@ class SilhouetteIoUFunction(Function):
 
     @staticmethod
     def forward(ctx, face_vertices, target, params):
-        faces, alpha, ws, tgt, sums = _forward(face_vertices, params, target)
+        faces, alpha, ws, tgt, sums, ctx.grad_faces = _forward(face_vertices, params, target, want_grad=ctx.needs_input_grad[0])
         ctx.params, ctx.shape, ctx.dtype = params, face_vertices.shape, face_vertices.dtype
         ctx.save_for_backward(faces, alpha, ws, tgt)
         ctx.mark_non_differentiable(alpha)
@@ -93,7 +104,8 @@ class SilhouetteIoUFunction(Function):
     @once_differentiable
     def backward(ctx, grad_sums, _grad_alpha_unused):
         faces, alpha, ws, tgt = ctx.saved_tensors
-        g = _backward(faces, alpha, ws, ctx.params, target=tgt, grad_iou=grad_sums.to(torch.float32).contiguous())
+        buf, ctx.grad_faces = ctx.grad_faces, None
+        g = _backward(faces, alpha, ws, ctx.params, target=tgt, grad_iou=grad_sums.to(torch.float32).contiguous(), grad_faces=buf)
         return g.reshape(ctx.shape).to(ctx.dtype), None, None
 
 

@@ -224,3 +224,46 @@ def test_multiview_reconstruction_step_through_the_alias_package(native_lib):
         assert vox.shape == (2 * Bm, 32, 32, 32) and 0 < vox.sum() < vox.size
         iou = (vox * vox).sum((1, 2, 3)) / (0 < (vox + vox)).sum((1, 2, 3))
         assert np.allclose(iou, 1.0)
+
+
+def test_gradients_cleared_by_the_forward_call_and_a_second_backward(native_lib):
+    """The Function hands gendr_forward the gradient buffers to clear (gendr_params.clear_ptr) and uses them once: a
+    second backward through the same graph must give the same gradients again, not their double."""
+    import scenes
+    from gendr_amd.functional import render
+    fv, tex = scenes.soup()
+    a = torch.from_numpy(fv).cuda().requires_grad_(True)
+    t = torch.from_numpy(tex).cuda().requires_grad_(True)
+    g = torch.randn(fv.shape[0], 4, 48, 48, device='cuda')
+    out = render(a, t, image_size=48)
+    ga1, gt1 = torch.autograd.grad(out, (a, t), g, retain_graph=True)
+    ga2, gt2 = torch.autograd.grad(out, (a, t), g)
+    # float atomics: the order of the per-tile sums differs from launch to launch
+    assert torch.allclose(ga1, ga2, rtol=1e-4, atol=1e-5 * float(ga1.abs().max()))
+    assert torch.allclose(gt1, gt2, rtol=1e-4, atol=1e-5 * float(gt1.abs().max()))
+    # inference: nothing allocated for gradients, same image
+    with torch.no_grad():
+        out2 = render(a, t, image_size=48)
+    assert torch.equal(out, out2)
+
+
+def test_clear_ptr_of_the_c_abi(native_lib):
+    import ctypes
+    import parity
+    import scenes
+    from gendr_amd.functional import renderer as R
+    fv, tex = scenes.soup()
+    o, extra = parity.split_options({})
+    p = parity.hip_params(48, o, extra)
+    faces = torch.from_numpy(fv).reshape(fv.shape[0], -1, 9).cuda()
+    textures = torch.from_numpy(tex).cuda()
+    buf = torch.full((4096 + 8,), float('nan'), device='cuda')
+    p.clear_ptr = buf.data_ptr() + 16
+    p.clear_floats = 4096
+    R.native_forward(faces, textures, p)
+    torch.cuda.synchronize()
+    b = buf.cpu()
+    assert torch.isnan(b[:4]).all() and torch.isnan(b[4100:]).all() and (b[4:4100] == 0).all()
+    p.clear_ptr = buf.data_ptr() + 4                       # not 16-byte aligned
+    with pytest.raises(Exception):
+        R.native_forward(faces, textures, p)
