@@ -77,6 +77,9 @@
 #define GENDR_SUM_LANES 1      // lanes per (face, component) segment in the backward sums: 1 or 4
 #endif
 
+#ifndef GENDR_COVER_INCREMENTAL
+#define GENDR_COVER_INCREMENTAL 1
+#endif
 #ifndef GENDR_COVER_REVERSE
 #define GENDR_COVER_REVERSE 1
 #endif
@@ -1132,6 +1135,12 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
         const float yp_a = pixel_coord(a.is - 1 - row_a, a.is, a.r_is);
         CoverEnt* out = a.entries + off;
         int nout = 0;
+#if GENDR_COVER_INCREMENTAL
+        float xs[8];                               // pixel centres of the tile's columns, and the nominal pixel pitch
+#pragma unroll
+        for (int c = 0; c < 8; c++) xs[c] = pixel_coord(t.x0 + c, a.is, a.r_is);
+        const float pitch = (float)(2. * a.r_is);
+#endif
         int my_pairs = 0;                          // pixels this lane's (face, row) slots found: summed into the tile's weight
 
         int word0 = 0, group0 = 0;                 // next 64-word group to load / base word of the loaded one
@@ -1166,6 +1175,31 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 float r[kRecStage1];
                 gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
                 unsigned m8 = 0u;
+#if GENDR_COVER_INCREMENTAL
+                // The entries only have to be a superset of the contributing pairs (every pair still meets the reference's
+                // own skip tests in the render kernels), so the barycentrics of a row are stepped from its first pixel
+                // instead of being evaluated eight times: w += a * pitch.  Against the expression the edge thresholds were
+                // derived for (barycentrics(), three roundings) the stepped value is off by at most a dozen roundings of
+                // magnitudes below |a| + |b| + |c| (|x|, |y| <= 1): the thresholds are lowered by 2^-20 of that sum --
+                // about 10^-4 pixel -- and a pixel is dropped only below them.  NaN and infinite coefficients drop nothing.
+                if (has && row_ok && !(yp_a > r[kRecBox + 3] || yp_a < r[kRecBox + 2])) {
+                    constexpr float kSlack = 9.5367431640625e-07f;                     // 2^-20
+                    float w0 = r[kRecInv + 0] * xs[0] + r[kRecInv + 1] * yp_a + r[kRecInv + 2];
+                    float w1 = r[kRecInv + 3] * xs[0] + r[kRecInv + 4] * yp_a + r[kRecInv + 5];
+                    float w2 = r[kRecInv + 6] * xs[0] + r[kRecInv + 7] * yp_a + r[kRecInv + 8];
+                    const float t0 = r[kRecWCull + 0] - kSlack * (fabsf(r[kRecInv + 0]) + fabsf(r[kRecInv + 1]) + fabsf(r[kRecInv + 2]));
+                    const float t1 = r[kRecWCull + 1] - kSlack * (fabsf(r[kRecInv + 3]) + fabsf(r[kRecInv + 4]) + fabsf(r[kRecInv + 5]));
+                    const float t2 = r[kRecWCull + 2] - kSlack * (fabsf(r[kRecInv + 6]) + fabsf(r[kRecInv + 7]) + fabsf(r[kRecInv + 8]));
+                    const float d0 = r[kRecInv + 0] * pitch, d1 = r[kRecInv + 3] * pitch, d2 = r[kRecInv + 6] * pitch;
+                    const float xlo = r[kRecBox + 0], xhi = r[kRecBox + 1];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const bool live = t.x0 + c < a.is && !(xs[c] > xhi || xs[c] < xlo) && !(w0 < t0 || w1 < t1 || w2 < t2);
+                        m8 |= (live ? 1u : 0u) << c;
+                        w0 += d0; w1 += d1; w2 += d2;
+                    }
+                }
+#else
                 if (has && row_ok) {
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
@@ -1179,6 +1213,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                         m8 |= (live ? 1u : 0u) << c;
                     }
                 }
+#endif
                 my_pairs += __popc(m8);
                 const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
                 const unsigned hi = (unsigned)__shfl_down((int)v, 4);                  // lane 8s reads lane 8s+4 (rows 4-7)
