@@ -64,7 +64,8 @@ typedef struct gendr_params {
     void* clear_ptr;               /* optional, gendr_forward / gendr_face_setup only: a float buffer the per-face setup */
     unsigned long long clear_floats;   /* kernel zero-fills on the way (16-byte aligned, a multiple of 4 floats) -- the
                                       gradient buffers of the coming gendr_backward call, which saves that call's
-                                      caller a fill launch.  NULL / 0: nothing is cleared. */
+                                      caller a fill launch.  NULL / 0: nothing is cleared.  Honoured by the float32
+                                      entry points (gendr_forward, gendr_silhouette_forward, gendr_face_setup) only. */
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward
