@@ -1,0 +1,42 @@
+"""Randomised HIP-vs-oracle check over shapes the fixed suites do not enumerate (run on the GPU box):
+    python tools/fuzz_parity.py [n_cases] [seed]
+Random batch size, face count (around the 64-face chunk boundaries), image size (odd sizes, sizes with empty 64x64
+super-tiles), texture layout and option set; the acceptance rule of tests/criteria.py; also culled == all-pairs."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import criteria, parity, scenes
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+names = [n for n, _ in scenes.OPTION_MATRIX]
+bad = 0
+for case in range(n_cases):
+    name, opts = scenes.OPTION_MATRIX[rs.randint(len(names))]
+    opts = dict(opts)
+    B = int(rs.choice([1, 2, 3, 5, 9]))
+    nf = int(rs.choice([1, 2, 17, 63, 64, 65, 127, 130, 200]))
+    isz = int(rs.choice([8, 13, 31, 64, 72, 100, 128, 136, 192, 200]))
+    vertex = opts.get('texture_type') == 'vertex'
+    T = 1 if vertex else int(rs.choice([1, 1, 4, 9]))
+    scale = float(rs.choice([0.25, 0.5, 1.0]))             # small scenes leave empty super-tiles
+    fv, tex = scenes.soup(B=B, nf=max(nf, 9), seed=int(rs.randint(1 << 30)), T=T, vertex_tex=vertex)
+    fv, tex = fv[:, :nf].copy(), tex[:, :nf].copy()
+    fv[..., :2] *= scale
+    if 'T' in opts:
+        opts.pop('T')
+    opts['T'] = T
+    res, h, r = parity.compare(fv, tex, isz, opts)
+    grad = np.random.RandomState(1).randn(B, 4, isz, isz).astype(np.float32)
+    noise = criteria.noise_floor(fv, tex, isz, opts, grad, oracle_f32=r)
+    fails = criteria.check(res, noise)
+    h2 = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
+    same = all(np.array_equal(h[k], h2[k], equal_nan=True) for k in ('rgba', 'aggrs_info'))
+    if not same:
+        fails.append('culled != all-pairs')
+    status = 'ok' if not fails else 'FAIL ' + '; '.join(fails)
+    bad += bool(fails)
+    print('%3d %-24s B=%d nf=%3d is=%3d T=%d scale=%.2f  rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, res['rgba']['max_rel'], status), flush=True)
+print('%d / %d cases failed' % (bad, n_cases))
+sys.exit(1 if bad else 0)
