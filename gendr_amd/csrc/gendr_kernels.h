@@ -390,11 +390,15 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         const double u = 5.9604644775390625e-08;
         const double vx[3] = {X0, X1, X2}, vy[3] = {Y0, Y1, Y2};
         const double vn[3] = {fabs(X0) + fabs(Y0), fabs(X1) + fabs(Y1), fabs(X2) + fabs(Y2)};
+        // one double reciprocal serves the nine quotients of the exact inverse and the three edge heights below: they
+        // feed an error BOUND that carries a factor of two and a 1/1024 margin, not a result (twelve double divisions
+        // were a third of this kernel's instructions, and its waves run alone on their SIMDs)
+        const double rdet = 1. / det;
         double delta[9], W[3], dw[3], wmax = 0.;
         for (int k = 0; k < 3; k++) {
             W[k] = 0.; dw[k] = 0.;
             for (int j = 0; j < 3; j++) {
-                delta[3 * k + j] = (double)g.inv[3 * k + j] - adj[3 * k + j] / det;
+                delta[3 * k + j] = (double)g.inv[3 * k + j] - adj[3 * k + j] * rdet;
                 W[k] += fabs((double)g.inv[3 * k + j]);
                 dw[k] += fabs(delta[3 * k + j]);
             }
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
             const double ex[3] = {X1 - X2, X2 - X0, X0 - X1}, ey[3] = {Y1 - Y2, Y2 - Y0, Y0 - Y1};
             for (int k = 0; k < 3; k++) {
                 const double len = sqrt(ex[k] * ex[k] + ey[k] * ey[k]);
-                const double wc = -(Rf * len / fabs(det)) * (1. + 1. / 1024.) - dw[k];
+                const double wc = -(Rf * len * fabs(rdet)) * (1. + 1. / 1024.) - dw[k];
                 if (wc == wc && wc > -1e30) wcull[k] = round_down(wc);
             }
         }
