@@ -66,26 +66,52 @@ EXPORTS = (
     "gendr_silhouette_workspace_bytes", "gendr_silhouette_forward", "gendr_silhouette_backward", "gendr_workspace_bytes_f64", "gendr_forward_f64", "gendr_backward_f64", "gendr_selftest", "gendr_light_faces", "gendr_light_faces_backward", "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
 )
 
-_lib = None
+_libs = {}
+# Build variant the render entry points use: "default" (libgendr_hip.so) or "exact" (libgendr_hip_exact.so, the backward
+# kernels with the reference's rounding on the gradient side, gendr_amd/build.py).  Process-wide default from
+# GENDR_VARIANT; tests switch it with `use_variant`.
+_active = os.environ.get("GENDR_VARIANT", "default")
 
 
 class NativeLibraryError(RuntimeError):
     pass
 
 
-def lib():
-    """Loads the library once.  Raises NativeLibraryError (never falls back) if it is absent or stale."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def variant_path(variant):
+    return LIB_PATH if variant == "default" else os.path.join(_HERE, "libgendr_hip_%s.so" % variant)
+
+
+class use_variant(object):
+    """``with use_variant('exact'): ...`` routes every native call inside through that build variant."""
+    def __init__(self, variant):
+        self.variant = variant
+
+    def __enter__(self):
+        global _active
+        self.prev, _active = _active, self.variant
+        return lib()
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self.prev
+        return False
+
+
+def lib(variant=None):
+    """Loads the library (of the active build variant) once.  Raises NativeLibraryError (never falls back) if it is
+    absent or stale."""
+    variant = variant or _active
+    if variant in _libs:
+        return _libs[variant]
+    path = variant_path(variant)
+    if not os.path.exists(path):
         raise NativeLibraryError(
             "gendr_amd: %s not found. Build it with `python -m gendr_amd.build` "
-            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % path)
+    L = ctypes.CDLL(path)
     for name in EXPORTS:
         if not hasattr(L, name):
-            raise NativeLibraryError("gendr_amd: %s does not export %s" % (LIB_PATH, name))
+            raise NativeLibraryError("gendr_amd: %s does not export %s" % (path, name))
     i, f, vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
     pp = ctypes.POINTER(GendrParams)
     L.gendr_abi_version.restype = i
@@ -154,8 +180,8 @@ def lib():
     if L.gendr_abi_version() != ABI_VERSION:
         raise NativeLibraryError("gendr_amd: ABI version mismatch (library %d, python %d); rebuild"
                                  % (L.gendr_abi_version(), ABI_VERSION))
-    _lib = L
-    return _lib
+    _libs[variant] = L
+    return L
 
 
 def error_string(code):

@@ -12,6 +12,17 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
+# Build variants.  "default" is the shipped library.  "exact" compiles the backward kernels with
+# -DGENDR_EXACT_GRADIENT=1: every gradient-side quotient, the gaussian / gamma densities and the t-conorm partials keep
+# the reference's own rounding and promotions (kernel.cu:1026-1052) -- the parity build SURVEY H1 asks for; the tests
+# and profiles/parity_r03.json compare the two against the oracle (tests/test_gpu_exact_gradient.py).
+VARIANTS = {"default": [], "exact": ["-DGENDR_EXACT_GRADIENT=1"]}
+
+
+def lib_path(variant="default"):
+    if variant not in VARIANTS:
+        raise ValueError("unknown build variant %r (have %s)" % (variant, sorted(VARIANTS)))
+    return LIB_PATH if variant == "default" else os.path.join(_HERE, "libgendr_hip_%s.so" % variant)
 SOURCES = ["gendr_capi.hip"]
 HEADERS = ["gendr_kernels.h", "gendr_math.h", "gendr_project.h", "gendr_voxel.h", "gendr_texture.h", "gendr_light.h", "gendr_f64.h", os.path.join("..", "..", "include", "gendr_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -25,39 +36,49 @@ def _hipcc():
     return exe
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def needs_build(variant="default"):
+    path = lib_path(variant)
+    if not os.path.exists(path):
         return True
-    built = os.path.getmtime(LIB_PATH)
+    built = os.path.getmtime(path)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile the library if it is missing or older than its sources; returns its path.  Safe when several
-    processes (one per GPU) call it at once: one compiles under a file lock into a temporary name and renames, the
-    others find the library up to date when they get the lock."""
-    if not (force or needs_build()):
-        return LIB_PATH
+def build(force=False, verbose=False, variant="default"):
+    """Compile the library (one build variant) if it is missing or older than its sources; returns its path.  Safe when
+    several processes (one per GPU) call it at once: one compiles under a file lock into a temporary name and renames,
+    the others find the library up to date when they get the lock."""
+    path = lib_path(variant)
+    if not (force or needs_build(variant)):
+        return path
     import fcntl
-    with open(LIB_PATH + ".lock", "w") as lock:
+    with open(path + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if force or needs_build():
-                tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
-                cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if force or needs_build(variant):
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                cmd = [_hipcc()] + HIPCC_FLAGS + VARIANTS[variant] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
                 if verbose:
-                    print(" ".join(cmd[:-1] + [LIB_PATH]))
+                    print(" ".join(cmd[:-1] + [path]))
                 try:
                     subprocess.check_call(cmd, cwd=CSRC)
-                    os.replace(tmp, LIB_PATH)
+                    os.replace(tmp, path)
                 finally:
                     if os.path.exists(tmp):
                         os.remove(tmp)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB_PATH
+    return path
+
+
+def build_all(force=False, verbose=False):
+    """Every variant, compiled side by side (each hipcc run is single-threaded)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(len(VARIANTS)) as ex:
+        return list(ex.map(lambda v: build(force=force, verbose=verbose, variant=v), sorted(VARIANTS)))
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build_all(force="--force" in sys.argv or len(sys.argv) == 1, verbose=True))

@@ -24,5 +24,5 @@ def oracle_mod():
 def native_lib():
     """libgendr_hip.so; built on demand (hipcc cross-compiles gfx950 without a GPU)."""
     from gendr_amd import build, _native
-    build.build()
+    build.build_all()
     return _native.lib()

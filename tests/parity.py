@@ -32,8 +32,13 @@ def hip_params(image_size, o, extra):
     return p
 
 
-def run_hip(fv, tex, image_size, opts, grad=None, device='cuda:0'):
-    """fv [B,nf,3,3], tex [B,nf,T,3] numpy.  Returns dict of numpy arrays."""
+def run_hip(fv, tex, image_size, opts, grad=None, device='cuda:0', variant=None):
+    """fv [B,nf,3,3], tex [B,nf,T,3] numpy.  Returns dict of numpy arrays.  `variant`: build variant of the library
+    ('default' / 'exact', gendr_amd/build.py); None = the process's active one."""
+    if variant is not None:
+        from gendr_amd import _native
+        with _native.use_variant(variant):
+            return run_hip(fv, tex, image_size, opts, grad, device)
     o, extra = split_options(opts)
     p = hip_params(image_size, o, extra)
     B, nf = fv.shape[:2]
