@@ -67,16 +67,6 @@
 #define GENDR_SPLIT_MIN 8
 #endif
 
-#ifndef GENDR_MFMA_SUMS
-#define GENDR_MFMA_SUMS 0      // 1: the per-face sums of the backward partials run on the matrix pipe (see render_backward_body).
-                               // Measured at C2: correct and deterministic, but 175 us instead of 137 us for the backward kernel
-                               // (one or two accumulators alike), so the scalar LDS loop stays the default.
-#endif
-
-#ifndef GENDR_SUM_LANES
-#define GENDR_SUM_LANES 1      // lanes per (face, component) segment in the backward sums: 1 or 4
-#endif
-
 #ifndef GENDR_BIN_CENTER_OUT
 #define GENDR_BIN_CENTER_OUT 1
 #endif
@@ -1050,10 +1040,9 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 // A pair in the batch list is one int, (face slot in the batch << 8) | pixel lane; its barycentrics are computed in
 // phase B from the gathered record and the pixel centre from the lane (the same expressions on the same operands as
 // everywhere else).
-struct FaceEnt {           // 16 bytes
+struct FaceSeg {           // 8 bytes: one face of a backward batch
     int fn;                // face index inside the batch item
-    int base;              // index of the face's first pair in the batch
-    unsigned long long mask;   // ballot of the pixels (lanes) that own a pair of this face
+    int span;              // (first pair of the face in the batch) | (its consecutive pairs << 8)
 };
 constexpr int kFlagContrib = 1;   // passed :769 and :784 -> folds into alpha
 constexpr int kFlagDepthOk = 2;   // near <= zp <= far (:810)
@@ -1309,17 +1298,27 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
     }
 }
 
-// Walks a tile's coverage entries in ascending face order and calls body(fn, mask, false) for each, then
-// body(0, 0, true) once (the caller flushes its open batch there) -- from ONE call site, so that the caller's phase B
-// is compiled once (two sites doubled the kernels' code).  64 entries arrive by one coalesced 16-byte load per lane; v_readlane hands them to the
-// (wave-uniform) body one by one.
-// A tile without a slice of the entry pool (off < 0) produces its entries here instead, up to 64 at a time: its
-// mask row is walked with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact
-// per-pixel tests (collect_pairs) -- same entries, only slower.
+// A tile's (pixel, face) pairs as a list of 4-byte codes (face << 6 | pixel lane), in ascending (face, pixel) order, built
+// in a wavefront-private LDS buffer from the tile's coverage entries, and handed to body(first code, pairs) in batches of
+// 64 consecutive codes -- lane l of phase B takes code l of the batch.  A batch is just a window of the list: faces are
+// split wherever the window ends, every batch but the tile's last is full.
+//   * entries arrive 64 at a time by one coalesced 16-byte load per lane; v_readlane hands (face, mask) to the wave-uniform
+//     append step: the lanes (= pixels) whose bit is set store their code at list position base + (set bits below the lane)
+//     -- ten instructions per entry, no per-batch bookkeeping (round 2 built the batches entry by entry with their face
+//     tables and split decisions: ~45 instructions per entry, and per tile that was as much as a batch of pair math);
+//   * entries are appended until at least kFillCodes are listed; the full batches run -- from ONE call site, so that the
+//     caller's phase B is compiled once -- and the remainder (< 64 codes) moves to the front of the buffer;
+//   * a tile without a slice of the entry pool (off < 0) produces its entries here instead, up to 64 at a time: its mask
+//     row is walked with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact per-pixel
+//     tests (collect_pairs) -- same entries, only slower.
+constexpr int kChunkBatches = 4;
+constexpr int kFillCodes = kChunkBatches * 64, kCodeCap = kFillCodes + 64;
+
 template <int REC, typename Body>
-__device__ __forceinline__ void for_each_entry(const RenderArgs& a, const TileCtx& t, int off, int cnt, Body body)
+__device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCtx& t, int off, int cnt, int* s_code, Body body)
 {
     const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int4* ents = reinterpret_cast<const int4*>(a.entries + max(off, 0));
     // state of the mask-row walk of the fallback
     const unsigned long long* mrow = a.masks + (long)t.tile * a.chunks;
@@ -1330,51 +1329,66 @@ __device__ __forceinline__ void for_each_entry(const RenderArgs& a, const TileCt
 
     int e0 = 0, n = 0, j = 0;
     int4 e = make_int4(0, 0, 0, 0);
+    int npairs = 0;                                  // codes in s_code[0, npairs)
+    bool done = false;
     for (;;) {
-        if (j == n) {
-            // ---- next chunk of up to 64 entries into lane-indexed registers
-            j = 0; n = 0;
-            if (off >= 0) {
-                n = min(64, cnt - e0);
-                if (lane < n) e = ents[e0 + lane];
-                e0 += n;
-            } else {
-                while (n < 64 && !exhausted) {
-                    if (!w) {
-                        if (!nz) {
-                            if (word0 >= a.chunks) { exhausted = true; break; }
-                            wv = word0 + lane < a.chunks ? mrow[word0 + lane] : 0ull;
-                            nz = __ballot(wv != 0ull);
-                            group0 = word0;
-                            word0 += 64;
+        // ---- fill: append entries until kFillCodes are listed or the tile's entries are used up
+        while (!done && npairs < kFillCodes) {
+            if (j == n) {
+                // next group of up to 64 entries into lane-indexed registers
+                j = 0; n = 0;
+                if (off >= 0) {
+                    n = min(64, cnt - e0);
+                    if (lane < n) e = ents[e0 + lane];
+                    e0 += n;
+                } else {
+                    while (n < 64 && !exhausted) {
+                        if (!w) {
+                            if (!nz) {
+                                if (word0 >= a.chunks) { exhausted = true; break; }
+                                wv = word0 + lane < a.chunks ? mrow[word0 + lane] : 0ull;
+                                nz = __ballot(wv != 0ull);
+                                group0 = word0;
+                                word0 += 64;
+                                continue;
+                            }
+                            const int jj = __builtin_ctzll(nz);
+                            nz &= nz - 1;
+                            w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), jj) << 32)
+                              | (unsigned)__builtin_amdgcn_readlane((int)wv, jj);
+                            wbase = (group0 + jj) * 64;
                             continue;
                         }
-                        const int jj = __builtin_ctzll(nz);
-                        nz &= nz - 1;
-                        w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), jj) << 32)
-                          | (unsigned)__builtin_amdgcn_readlane((int)wv, jj);
-                        wbase = (group0 + jj) * 64;
-                        continue;
-                    }
-                    const int fn = wbase + __builtin_ctzll(w);
-                    w &= w - 1;
-                    Pair q;
-                    const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
-                    if (m) {
-                        if (lane == n) e = make_int4(fn, 0, (int)(unsigned)m, (int)(unsigned)(m >> 32));
-                        n++;
+                        const int fn = wbase + __builtin_ctzll(w);
+                        w &= w - 1;
+                        Pair q;
+                        const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
+                        if (m) {
+                            if (lane == n) e = make_int4(fn, 0, (int)(unsigned)m, (int)(unsigned)(m >> 32));
+                            n++;
+                        }
                     }
                 }
+                if (n <= 0) { done = true; break; }
             }
+            const int fn = __builtin_amdgcn_readlane(e.x, j);
+            const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j);
+            j++;
+            if ((m >> lane) & 1ull) s_code[npairs + __popcll(m & lt)] = (fn << 6) | lane;
+            npairs += __popcll(m);
         }
-        // one call site: the flush is an entry like any other
-        const bool flush = n <= 0;
-        const int fn = flush ? 0 : __builtin_amdgcn_readlane(e.x, j);
-        const unsigned long long m = flush ? 0ull
-            : (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j));
-        j++;
-        body(fn, m, flush);
-        if (flush) return;
+        // ---- drain: the full batches, and at the end of the tile the partial one
+        const int nb = done ? (npairs + 63) >> 6 : npairs >> 6;
+        if (nb == 0) break;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < nb; k++) body(k << 6, min(64, npairs - (k << 6)));
+        if (done) break;
+        const int rem = npairs - (nb << 6);
+        __builtin_amdgcn_wave_barrier();
+        const int keep = lane < rem ? s_code[(nb << 6) + lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) s_code[lane] = keep;
+        npairs = rem;
     }
 }
 
@@ -1395,10 +1409,10 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int WAVES = kThreads / 64;
-    __shared__ int s_pair[WAVES][64];
+    __shared__ int s_code[WAVES][kCodeCap];                 // the tile's pair list (face << 6 | pixel), see for_each_batch
     __shared__ float2 s_xy[WAVES][64];                      // pixel centres of the tile, fetched by pair lanes
     __shared__ __attribute__((aligned(16))) FwdRes  s_res[WAVES][64];
-    __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
+    __shared__ unsigned long long s_mask[WAVES][64];        // per pixel: which pairs of the running batch are its own
 
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
@@ -1497,18 +1511,23 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     int face_min = -1;
 
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
-    int npairs = 0, nfaces = 0;
-    unsigned long long my_pairs = 0ull;        // bit i: pair i of the open batch belongs to this lane's pixel
 
-    auto run_batch = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_wave_barrier();
+    auto run_batch = [&](int base, int np) __attribute__((always_inline)) {
 #if GENDR_ABLATE == 1
-        alpha += (float)npairs; npairs = 0; nfaces = 0; my_pairs = 0ull; return;
+        alpha += (float)np; return;
 #endif
+        // Which pairs of the batch are this pixel's?  Every pair lane sets its bit in its pixel's word: a 64-bit LDS OR
+        // (the few pairs of one pixel -- one per face of the batch -- serialise on their word, different pixels do not).
+        s_mask[wave][lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        int code = 0;
+        if (lane < np) {
+            code = s_code[wave][base + lane];
+            __hip_atomic_fetch_or(&s_mask[wave][code & 63], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
         // ---- phase B: one pair per lane
-        if (lane < npairs) {
-            const int code = s_pair[wave][lane];
-            const int fn = s_face[wave][code >> 8].fn;
+        if (lane < np) {
+            const int fn = code >> 6;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
             const float* rg = recs_g + (long)fn * REC;
@@ -1547,10 +1566,10 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         }
         __builtin_amdgcn_wave_barrier();
 #if GENDR_ABLATE == 2
-        alpha += s_res[wave][lane].frag; npairs = 0; nfaces = 0; my_pairs = 0ull; return;
+        alpha += s_res[wave][lane].frag; return;
 #endif
         // ---- phase C: every pixel folds its own pairs; their list positions ascend with the face index
-        for (unsigned long long todo = my_pairs; todo; todo &= todo - 1) {
+        for (unsigned long long todo = s_mask[wave][lane]; todo; todo &= todo - 1) {
             const FwdRes res = s_res[wave][__builtin_ctzll(todo)];
             const int fn = res.fn;
             if (!(res.flags & kFlagContrib)) continue;
@@ -1586,39 +1605,10 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
                 col[2] = edz * col[2] + ez * res.frag * res.c2;
             }
         }
-        npairs = 0;
-        nfaces = 0;
-        my_pairs = 0ull;
+        __builtin_amdgcn_wave_barrier();
     };
 
-    for_each_entry<REC>(a, t, ti.y, ti.z, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
-        auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
-            if ((mm >> lane) & 1ull) {
-                const int at = npairs + __popcll(mm & lt);
-                s_pair[wave][at] = (nfaces << 8) | lane;
-                my_pairs |= 1ull << at;
-            }
-            if (lane == 0) {
-                FaceEnt fe;
-                fe.fn = fn; fe.base = npairs; fe.mask = mm;
-                s_face[wave][nfaces] = fe;
-            }
-            npairs += __popcll(mm);
-            nfaces += 1;
-        };
-        if (flush ? npairs > 0 : npairs + __popcll(m) > 64) {
-            // top the batch up with the first pairs of this face (its pixels stay in ascending-face order: the rest
-            // of the face opens the next batch), unless the room left is not worth a second list entry
-            const int room = 64 - npairs;
-            if (!flush && room >= kSplitMin) {
-                const unsigned long long m1 = __ballot(((m >> lane) & 1ull) && __popcll(m & lt) < room);
-                emit(m1);
-                m &= ~m1;
-            }
-            run_batch();
-        }
-        if (!flush) emit(m);
-    });
+    for_each_batch<REC>(a, t, ti.y, ti.z, s_code[wave], run_batch);
 
     if constexpr (kSil) {
         // alpha plane, and the tile's share of the fused IoU sums (opt_shape.py:20-24: intersect = sum(a t),
@@ -1703,19 +1693,10 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     constexpr int NG = GradSlots<TEXM>::n;       // 9 vertex components, then texture components summed per face in LDS
     constexpr int NT = NG > 9 ? NG - 9 : 1;
     constexpr int WAVES = kThreads / 64;
-    __shared__ int s_pair[WAVES][64];
+    __shared__ int s_code[WAVES][kCodeCap];      // the tile's pair list (face << 6 | pixel), see for_each_batch
     __shared__ __attribute__((aligned(16))) PixIn   s_pix[WAVES][64];
-    __shared__ __attribute__((aligned(16))) FaceEnt s_face[WAVES][64];
-#if GENDR_MFMA_SUMS
-    // per-pair gradient partials, one row per pair: kColBlocks blocks of 16 components, rows 4 floats apart from a
-    // multiple of 16 and the four 16-row groups another 16 floats apart -- 16-byte row stores and the matrix
-    // operand reads below are both free of bank conflicts
-    constexpr int kColBlocks = (NG + 15) / 16;
-    constexpr int kRowStride = 16 * kColBlocks + 4;
-    __shared__ __attribute__((aligned(16))) float s_val[WAVES][64 * kRowStride + 48];
-#else
+    __shared__ __attribute__((aligned(8))) FaceSeg s_seg[WAVES][64];   // the faces of the running batch: (face, first pair, pairs)
     __shared__ float s_val[WAVES][NG * 65];      // per-pair gradient partials, component-major, rows padded to 65
-#endif
 
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
@@ -1779,29 +1760,33 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 #endif
 
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
-    int npairs = 0, nfaces = 0;
 
-    auto run_batch = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_wave_barrier();
-        GENDR_T(2);                               // 2: entry list + emit since the last batch
+    auto run_batch = [&](int base, int np) __attribute__((always_inline)) {
+        GENDR_T(2);                               // 2: entry list + code list since the last batch
 #if GENDR_TRACE
         if (!tr[3]) GENDR_STAMP(3);
         tr[5] += 1;
 #endif
 #if GENDR_ABLATE == 3
-        npairs = 0; nfaces = 0; return;
+        return;
 #endif
-        float gv_b[9], gt_b[NT];                  // this lane's partials, handed to the per-face sums below
-        bool live_b = false;
-#pragma unroll
-        for (int k = 0; k < 9; k++) gv_b[k] = 0.f;
-#pragma unroll
-        for (int k = 0; k < NT; k++) gt_b[k] = 0.f;
-        if (lane < npairs) {
-            const int code = s_pair[wave][lane];
-            const int slot = code >> 8;
+        // The batch's codes, and its faces: the pairs of one face are consecutive, so a lane whose face differs from
+        // its left neighbour's heads a segment; the ballot of the heads gives every head its slot, first pair and
+        // length (a dozen vector instructions per batch for what the entry-by-entry batch builder used to keep).
+        const int code = lane < np ? s_code[wave][base + lane] : -64;
+        const int fn_l = code >> 6;
+        const int fn_left = __builtin_amdgcn_update_dpp(-2, fn_l, 0x138, 0xF, 0xF, false);     // wave_shr:1, lane 0 keeps -2
+        const unsigned long long heads = __ballot(lane < np && fn_l != fn_left);
+        const int nfaces = __popcll(heads);
+        if ((heads >> lane) & 1ull) {
+            const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
+            FaceSeg sg;
+            sg.fn = fn_l; sg.span = lane | ((above ? __builtin_ctzll(above) + 1 : np - lane) << 8);
+            s_seg[wave][__popcll(heads & lt)] = sg;
+        }
+        if (lane < np) {
             const PixIn px = s_pix[wave][code & 63];
-            const int fn = s_face[wave][slot].fn;
+            const int fn = fn_l;
             const long face_lin = (long)t.b * a.nf + fn;
             float r[REC];
             const float* rg = recs_g + (long)fn * REC;
@@ -1964,12 +1949,6 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
                 }
             }
             GENDR_T(4);                           // 4: the pair math (incl. the second gather)
-            live_b = live;
-#pragma unroll
-            for (int k = 0; k < 9; k++) gv_b[k] = gv[k];
-#pragma unroll
-            for (int k = 0; k < NT; k++) gt_b[k] = gt[k];
-#if !GENDR_MFMA_SUMS
             // every pair lane publishes its partials (zeros if the pair dropped out): column = pair index
 #pragma unroll
             for (int k = 0; k < 9; k++) asm("" : "+v"(gv[k]));
@@ -1979,138 +1958,19 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             for (int k = 0; k < 9; k++) s_val[wave][k * 65 + lane] = live ? gv[k] : 0.f;
 #pragma unroll
             for (int k = 0; k < NG - 9; k++) s_val[wave][(9 + k) * 65 + lane] = live ? gt[k] : 0.f;
-#endif
-        }
-#if GENDR_MFMA_SUMS
-        // ---- per-face sums on the matrix pipe.
-        // S[slot][comp] = sum over the batch's pairs of Ind[slot][pair] * V[pair][comp] with Ind = 1 where the pair
-        // belongs to the face in that slot: a 16 x 64 by 64 x 16 product per (16 slots, 16 components), i.e. sixteen
-        // v_mfma_f32_16x16x4_f32.  f32 in, f32 accumulate: each step is fma(1 or 0, v, acc), bit for bit a sequential
-        // f32 sum in a fixed pair order -- deterministic inside the batch like the scalar loop it replaces, but without
-        // its chain of dependent LDS round trips (the longest face of the batch used to set the trip count), and on a
-        // pipe nothing else in this kernel uses: the VALU is free for the other waves meanwhile.
-        // 0 * inf would poison the other faces' sums, so a pair with a non-finite partial (degenerate faces) zeroes its
-        // row and adds its values itself.
-        {
-            float vals[16 * kColBlocks];
-#pragma unroll
-            for (int k = 0; k < 16 * kColBlocks; k++) vals[k] = 0.f;
-            bool mine = false;
-            if (lane < npairs && live_b) {
-                float chk = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; k++) { vals[k] = gv_b[k]; chk += fabsf(gv_b[k]); }
-#pragma unroll
-                for (int k = 0; k < NG - 9; k++) { vals[9 + k] = gt_b[k]; chk += fabsf(gt_b[k]); }
-                mine = !(chk < INFINITY);
-            }
-            if (mine) {
-                const long face_lin = (long)t.b * a.nf + s_face[wave][s_pair[wave][lane] >> 8].fn;
-#pragma unroll
-                for (int k = 0; k < NG; k++) {
-                    if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, vals[k]);
-                    else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), vals[k]);
-                    vals[k] = 0.f;
-                }
-            }
-            float* row = &s_val[wave][lane * kRowStride + (lane >> 4) * 16];
-#pragma unroll
-            for (int c = 0; c < 4 * kColBlocks; c++)
-                reinterpret_cast<float4*>(row)[c] = make_float4(vals[4 * c], vals[4 * c + 1], vals[4 * c + 2], vals[4 * c + 3]);
         }
         __builtin_amdgcn_wave_barrier();
         GENDR_T(5);                               // 5: partials to LDS
 #if GENDR_ABLATE == 4
-        npairs = 0; nfaces = 0; return;
+        return;
 #endif
-        {
-            const int grp = lane >> 4, sub = lane & 15;
-            // face slots of this lane group's sixteen pairs (rows of pairs beyond npairs are zero: their slot is irrelevant)
-            int sl[16];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int4 c4 = reinterpret_cast<const int4*>(&s_pair[wave][16 * grp])[q];
-                sl[4 * q] = c4.x >> 8; sl[4 * q + 1] = c4.y >> 8; sl[4 * q + 2] = c4.z >> 8; sl[4 * q + 3] = c4.w >> 8;
-            }
-            const float* vbase = &s_val[wave][(16 * grp) * kRowStride + grp * 16 + sub];
-            for (int pass = 0; pass * 16 < nfaces; pass++) {
-#pragma unroll
-                for (int cb = 0; cb < kColBlocks; cb++) {
-                    // two accumulators: consecutive steps do not wait for each other's 40-cycle result
-                    mf4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-                    float bv[16], iv[16];
-#pragma unroll
-                    for (int st = 0; st < 16; st++) {
-                        iv[st] = (sl[st] == sub + 16 * pass) ? 1.f : 0.f;
-                        bv[st] = vbase[st * kRowStride + cb * 16];
-                    }
-#pragma unroll
-                    for (int st = 0; st < 16; st += 2) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(iv[st], bv[st], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(iv[st + 1], bv[st + 1], acc2, 0, 0, 0);
-                    }
-                    acc += acc2;
-                    const int comp = cb * 16 + sub;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int slot = 16 * pass + 4 * grp + i;
-                        const float v = acc[i];
-#if GENDR_ABLATE == 8
-                        if (v == 12345.678f) {
-#else
-                        if (slot < nfaces && comp < NG && v != 0.f) {
-#endif
-                            const long face_lin = (long)t.b * a.nf + s_face[wave][slot].fn;
-                            if (comp < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + comp, v);
-                            else          unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (comp - 9), v);
-                        }
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#else
-        __builtin_amdgcn_wave_barrier();
-        GENDR_T(5);                               // 5: partials to LDS
-#if GENDR_ABLATE == 4
-        npairs = 0; nfaces = 0; return;
-#endif
-#if GENDR_SUM_LANES == 4
-        // The pairs of one face are contiguous.  Four lanes per (face, component): each sums every fourth value of the
-        // segment (the four read neighbouring addresses), a two-step quad reduction combines them and the first lane
-        // issues one hardware fp32 atomic -- deterministic inside the batch, no LDS atomics, and a quarter of the
-        // dependent LDS round trips of one lane per segment (the longest face of the batch sets the trip count).
-        for (int e = lane; e < nfaces * NG * 4; e += 64) {
-            const int sub = e & 3, item = e >> 2;
-            const int slot = item / NG, k = item - slot * NG;
-            const FaceEnt fe = s_face[wave][slot];
-            const int cnt = __popcll(fe.mask);
-            const float* col = &s_val[wave][k * 65 + fe.base];
-            float v0 = 0.f, v1 = 0.f;
-            int i = sub;
-            for (; i + 4 < cnt; i += 8) { v0 += col[i]; v1 += col[i + 4]; }
-            if (i < cnt) v0 += col[i];
-            float v = v0 + v1;
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-#if GENDR_ABLATE == 8
-            if (v == 12345.678f) {
-#else
-            if (sub == 0 && v != 0.f) {
-#endif
-                const long face_lin = (long)t.b * a.nf + fe.fn;
-                if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
-                else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
-            }
-        }
-#else
         // The pairs of one face are contiguous.  One lane per (face, component) sums its segment in pair order and
         // issues one hardware fp32 atomic: deterministic inside the batch, no LDS atomics.
         for (int e = lane; e < nfaces * NG; e += 64) {
             const int slot = e / NG, k = e - slot * NG;
-            const FaceEnt fe = s_face[wave][slot];
-            const int cnt = __popcll(fe.mask);
-            const float* col = &s_val[wave][k * 65 + fe.base];
+            const FaceSeg sg = s_seg[wave][slot];
+            const int cnt = sg.span >> 8;
+            const float* col = &s_val[wave][k * 65 + (sg.span & 255)];
             // four independent partial sums so that the LDS reads of a segment overlap instead of chaining
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
             int i = 0;
@@ -2122,41 +1982,16 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 #else
             if (v != 0.f) {
 #endif
-                const long face_lin = (long)t.b * a.nf + fe.fn;
+                const long face_lin = (long)t.b * a.nf + sg.fn;
                 if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
                 else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
             }
         }
-#endif
         __builtin_amdgcn_wave_barrier();
-#endif
         GENDR_T(6);                               // 6: segment sums + atomics issued
-        npairs = 0;
-        nfaces = 0;
     };
 
-    for_each_entry<REC>(a, t, ti.y, ti.z, [&](int fn, unsigned long long m, bool flush) __attribute__((always_inline)) {
-        auto emit = [&](unsigned long long mm) __attribute__((always_inline)) {
-            if ((mm >> lane) & 1ull) s_pair[wave][npairs + __popcll(mm & lt)] = (nfaces << 8) | lane;
-            if (lane == 0) {
-                FaceEnt fe;
-                fe.fn = fn; fe.base = npairs; fe.mask = mm;
-                s_face[wave][nfaces] = fe;
-            }
-            npairs += __popcll(mm);
-            nfaces += 1;
-        };
-        if (flush ? npairs > 0 : npairs + __popcll(m) > 64) {
-            const int room = 64 - npairs;                       // top the batch up, see render_forward_body
-            if (!flush && room >= kSplitMin) {
-                const unsigned long long m1 = __ballot(((m >> lane) & 1ull) && __popcll(m & lt) < room);
-                emit(m1);
-                m &= ~m1;
-            }
-            run_batch();
-        }
-        if (!flush) emit(m);
-    });
+    for_each_batch<REC>(a, t, ti.y, ti.z, s_code[wave], run_batch);
     __builtin_amdgcn_wave_barrier();
     GENDR_T(7);                                   // 7: tail of the tile (entry walk after the last batch)
     }   // tile loop

@@ -43,6 +43,7 @@ class _COpts(ctypes.Structure):
         ("aggr_rgb_eps", ctypes.c_float), ("aggr_rgb_gamma", ctypes.c_float),
         ("near_", ctypes.c_float), ("far_", ctypes.c_float), ("double_side", ctypes.c_int),
         ("texture_type", ctypes.c_int), ("texel_mode", ctypes.c_int), ("num_threads", ctypes.c_int),
+        ("prob_threshold_scale", ctypes.c_float),
     ]
 
 
@@ -85,6 +86,8 @@ def lib():
         L.gendr_oracle_count_pairs_f32.argtypes = [vp, vp, i, i, po]
         L.gendr_oracle_count_pairs_f32.restype = ctypes.c_longlong
         L.gendr_oracle_max_threads.restype = i
+        L.gendr_oracle_set_libm_jitter.restype = None
+        L.gendr_oracle_set_libm_jitter.argtypes = [i]
         _lib = L
     return _lib
 
@@ -96,7 +99,7 @@ def _opt(value, table):
 def make_opts(image_size=256, dist_func='uniform', dist_scale=1e-2, dist_squared=False, dist_shape=None,
               dist_shift=None, dist_eps=1e4, aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=None,
               aggr_rgb_func='softmax', aggr_rgb_eps=1e-3, aggr_rgb_gamma=1e-3, near=1, far=100,
-              double_side=True, texture_type='surface', texel_mode=0, num_threads=0):
+              double_side=True, texture_type='surface', texel_mode=0, num_threads=0, prob_threshold_scale=1.0):
     """Same option names and defaults as ``gendr.functional.render``
     (``functional/renderer.py:239-264``); ``None`` parameters become 0.0."""
     o = _COpts()
@@ -118,6 +121,7 @@ def make_opts(image_size=256, dist_func='uniform', dist_scale=1e-2, dist_squared
     o.texture_type = int(_opt(texture_type, TEXTURE_TYPES))
     o.texel_mode = int(texel_mode)
     o.num_threads = int(num_threads)
+    o.prob_threshold_scale = float(prob_threshold_scale)     # sensitivity analysis only, see gendr_oracle.h
     return o
 
 
@@ -176,6 +180,20 @@ def count_pairs(faces, opts):
     faces = np.ascontiguousarray(faces, dtype=np.float32).reshape(B, nf, 9)
     info = face_info(faces, np.float32)
     return int(lib().gendr_oracle_count_pairs_f32(_p(faces), _p(info), B, nf, ctypes.byref(opts)))
+
+
+class libm_jitter(object):
+    """``with libm_jitter(+1): ...``: every single-precision libm result of the float oracle moves one ulp up (-1: down)
+    inside the block -- the sensitivity runs of tests/criteria.py."""
+    def __init__(self, j):
+        self.j = int(j)
+
+    def __enter__(self):
+        lib().gendr_oracle_set_libm_jitter(self.j)
+
+    def __exit__(self, *exc):
+        lib().gendr_oracle_set_libm_jitter(0)
+        return False
 
 
 def max_threads():

@@ -18,17 +18,49 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* ---- libm jitter (sensitivity analysis of the parity tests only) ---------------------------------
+ * The float instantiation calls its single-precision libm functions through these wrappers.  With
+ * g_libm_jitter == 0 (always, except inside tests/criteria.py's sensitivity runs) they return the
+ * library's value unchanged.  With +1 / -1 every result is moved one ulp up / down: what a different
+ * but equally valid libm (the GPU's: <= 1-2 ulp, glibc: <= 1 ulp) can do to every element of the
+ * output.  Correctly rounded operations (+ - * / sqrt) are never touched. */
+static int g_libm_jitter = 0;
+void gendr_oracle_set_libm_jitter(int j) { g_libm_jitter = j > 7 ? 7 : (j < -7 ? -7 : j); }
+static inline float jit(float v, float arg)
+{
+    if (g_libm_jitter == 0 || !(v == v) || v == INFINITY || v == -INFINITY) return v;
+    int up = g_libm_jitter > 0;
+    if (g_libm_jitter >= 2 || g_libm_jitter <= -2) {
+        /* +-2 ... +-7: the direction is one of six bits of a hash of the result's bit pattern (and its complement): neighbouring pairs move
+         * AGAINST each other, which is what changes a ratio of two fragments (softmax weights) */
+        unsigned u, a;                     /* result AND argument: equal results of different pairs still move apart */
+        memcpy(&u, &v, sizeof u);
+        memcpy(&a, &arg, sizeof a);
+        u = (u ^ (a * 0x9e3779b9u)) * 2654435761u;
+        up ^= (int)((u >> (13 + (g_libm_jitter > 0 ? g_libm_jitter : -g_libm_jitter))) & 1u);
+    }
+    return nextafterf(v, up ? INFINITY : -INFINITY);
+}
+static inline float j_expf(float x) { return jit(expf(x), x); }
+static inline float j_logf(float x) { return jit(logf(x), x); }
+static inline float j_powf(float x, float y) { return jit(powf(x, y), x + y); }
+static inline float j_asinf(float x) { return jit(asinf(x), x); }
+static inline float j_coshf(float x) { return jit(coshf(x), x); }
+static inline float j_erfcf(float x) { return jit(erfcf(x), x); }
+static inline float j_atanf(float x) { return jit(atanf(x), x); }
+
 /* ---- float instantiation ------------------------------------------------ */
 #define S float
 #define FN(name) name##_f32
-#define S_exp expf
-#define S_log logf
-#define S_pow powf
+#define S_exp j_expf
+#define S_log j_logf
+#define S_pow j_powf
 #define S_sqrt sqrtf
-#define S_asin asinf
-#define S_cosh coshf
+#define S_asin j_asinf
+#define S_cosh j_coshf
+#define S_atanf j_atanf
 /* CUDA normcdff(x); restated as erfc form (published definition of the normal CDF) */
-#define S_ncdf(x) (0.5f * erfcf(-(x) * 0.70710678118654752440f))
+#define S_ncdf(x) (0.5f * j_erfcf(-(x) * 0.70710678118654752440f))
 #include "gendr_oracle_body.inc"
 #undef S
 #undef FN
@@ -39,6 +71,7 @@
 #undef S_asin
 #undef S_cosh
 #undef S_ncdf
+#undef S_atanf
 
 /* ---- double instantiation ----------------------------------------------- */
 #define S double
@@ -49,6 +82,7 @@
 #define S_sqrt sqrt
 #define S_asin asin
 #define S_cosh cosh
+#define S_atanf atanf
 #define S_ncdf(x) (0.5 * erfc(-(x) * 0.70710678118654752440))
 #include "gendr_oracle_body.inc"
 #undef S

@@ -57,6 +57,11 @@ typedef struct {
      *            1 = clamp the texel index to the face's own R x R block. */
     int   texel_mode;
     int   num_threads;            /* OpenMP threads; <=0 -> runtime default */
+    /* Sensitivity analysis only (tests/criteria.py): the contribution threshold of kernel.cu:13,:784 is
+     * multiplied by this factor; <= 0 means 1 (0.000001 * 1.0 is exact, so the default is the reference's
+     * comparison bit for bit).  Elements whose value changes when the threshold moves by a few percent are
+     * decided by last-ulp libm differences and are reported separately by the parity tests. */
+    float prob_threshold_scale;
 } gendr_oracle_opts;
 
 /* scalar functions, float instantiation (kernel.cu:1230-1270) */
@@ -108,6 +113,10 @@ long long gendr_oracle_count_pairs_f32(const float* faces, const float* faces_in
                                        int B, int nf, const gendr_oracle_opts* o);
 
 int gendr_oracle_max_threads(void);
+/* sensitivity analysis only: +1 / -1 moves every single-precision libm result of the float instantiation one ulp up /
+ * down, +-2 ... +-7 up or down by (six different bits of) a hash of the
+ * result's bits (neighbouring pairs move against each other), 0 (the default) leaves it alone (gendr_oracle.c).  Process-wide; not to be changed while a call is running. */
+void gendr_oracle_set_libm_jitter(int j);
 
 #ifdef __cplusplus
 }

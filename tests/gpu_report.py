@@ -4,9 +4,10 @@
 
 For every option set of the matrix on the three test scenes, and for BASELINE configs C2..C5 at their full image
 size (one frame each), per tensor: max / p99 relative error, fraction above 1e-5, fraction bit-identical -- for rgba,
-alpha, aggrs_info, the raw gradients (error / |reference element|) and the conditioned gradients (error / sum of
-|contributions|) -- with the oracle's own fp32-vs-fp64 spread (the noise floor of tests/criteria.py) beside it, the
-verdict of the acceptance rule, and whether the culled traversal is bit-identical to the all-pairs one."""
+aggrs_info and the gradients, for BOTH build variants (default: fp32-accurate gradient side; exact: the reference's
+rounding, -DGENDR_EXACT_GRADIENT=1), the report of the element-wise acceptance rule (tests/criteria.py: violations, how
+many elements are not held to 1e-5 and why), the conditioned gradient error (error / sum of |contributions|), default
+vs exact directly, and whether the culled traversal is bit-identical to the all-pairs one."""
 import json
 import os
 import subprocess
@@ -30,28 +31,59 @@ FULL = {
 }
 
 
-def one_case(fv, tex, isz, opts, with_cull_check=True):
-    res, h, r = parity.compare(fv, tex, isz, opts)
+VARIANTS = ('default', 'exact')
+
+
+def one_case(fv, tex, isz, opts, with_cull_check=True, n_jitter=len(criteria.JITTER_MODES)):
+    """Both build variants against the oracle under the element-wise rule (tests/criteria.py)."""
     grad = np.random.RandomState(1).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
-    noise = criteria.noise_floor(fv, tex, isz, opts, grad, oracle_f32=r)
-    entry = dict(hip_vs_oracle=res, oracle_fp32_vs_fp64=noise, accepted=not criteria.check(res, noise),
-                 failures=criteria.check(res, noise))
+    refs = criteria.references(fv, tex, isz, opts, grad, n_jitter=n_jitter)
+    o32 = refs['o32']
+    entry = dict(variants={})
+    hips = {}
+    for v in VARIANTS:
+        h = hips[v] = parity.run_hip(fv, tex, isz, opts, grad, variant=v)
+        rep = criteria.elementwise(h, refs)
+        bad = criteria.failures(rep)
+        cond = {k: parity.stats(h[k], o32[k], scale=o32[ak]) for k, ak in criteria.GRAD_KEYS}
+        entry['variants'][v] = dict(elementwise=rep, accepted=not bad, failures=bad,
+                                    grad_faces_cond=cond['grad_faces'], grad_textures_cond=cond['grad_textures'])
+    # how much of the deviation is the relaxed gradient arithmetic: default vs exact, relative to the sum of |contributions|
+    entry['default_vs_exact'] = {k: parity.stats(hips['default'][k], hips['exact'][k], scale=o32[ak].reshape(hips['exact'][k].shape))
+                                 for k, ak in criteria.GRAD_KEYS}
+    entry['rgba'] = parity.stats(hips['default']['rgba'], o32['rgba'])
+    entry['oracle_fp32_vs_fp64'] = dict(rgba=parity.stats(o32['rgba'], refs['o64']['rgba']),
+                                        grad_faces_cond=parity.stats(o32['grad_faces'], refs['o64']['grad_faces'], scale=refs['o64']['abs_faces']))
+    entry['accepted'] = all(e['accepted'] for e in entry['variants'].values())
     if with_cull_check:
-        h2 = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
+        h, h2 = hips['default'], parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
         entry['cull_identical'] = bool(all(np.array_equal(h[k], h2[k], equal_nan=True) for k in ('rgba', 'aggrs_info')))
         entry['grad_cull_maxdiff_rel'] = max(
             float(np.nanmax(np.abs(h[k] - h2[k])) / max(1e-30, float(np.nanmax(np.abs(h2[k]))))) for k in ('grad_faces', 'grad_textures'))
-    return entry, res
+    return entry
+
+
+def short(name, entry):
+    parts = [name]
+    for v in VARIANTS:
+        e = entry['variants'][v]
+        parts.append('%s: %s gf max %.1e p99 %.1e >1e-5 %.1e' % (v, 'ok' if e['accepted'] else 'REJECTED', e['grad_faces_cond']['max_rel'],
+                                                               e['grad_faces_cond']['p99_rel'], e['grad_faces_cond']['frac_gt_1e5']))
+    parts.append('d-vs-e %.1e' % entry['default_vs_exact']['grad_faces']['max_rel'])
+    parts.append('rgba max %.1e' % entry['rgba']['max_rel'])
+    return ' | '.join(parts)
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
     try:
         head = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
         head = None
     out = dict(tag=tag, head=head, date=time.strftime('%Y-%m-%d %H:%M:%S'),
-               metric='rel = |hip - oracle| / max(|oracle|, 1e-6 max|oracle|); *_cond: denominator also >= sum of |contributions|',
+               rule='element-wise: |hip - o32| <= max(1e-5 scale, %g libm-jitter noise, %g threshold flip), tests/criteria.py; '
+                    '*_cond: |hip - o32| / max(|o32|, sum of |contributions|)' % (criteria.K_NOISE, criteria.K_FLIP),
+               variants='default = shipped build (fp32-accurate gradient side); exact = -DGENDR_EXACT_GRADIENT=1 (reference rounding)',
                matrix={}, full_size={})
     for scene_name, maker, isz in (("soup", scenes.soup, 48), ("sphere", scenes.sphere, 64), ("slivers", scenes.slivers, 64)):
         for name, opts in scenes.OPTION_MATRIX:
@@ -61,23 +93,28 @@ def main():
             if 'T' in opts:
                 kw['T'] = opts['T']
             fv, tex = maker(**kw)
-            entry, res = one_case(fv, tex, isz, opts)
-            print(parity.fmt(scene_name + ':' + name, res), 'ok' if entry['accepted'] else 'REJECTED', flush=True)
+            entry = one_case(fv, tex, isz, opts)
+            print(short(scene_name + ':' + name, entry), flush=True)
             out['matrix'][scene_name + ':' + name] = entry
     from gendr_amd.synthetic import benchmark_scene
+    only = [a for a in sys.argv[2:]]
     for name, (isz, texture, opts) in FULL.items():
+        if only and name not in only:
+            continue
         fv, tex = benchmark_scene(3, texture=texture)
         fv, tex = fv.numpy()[2:3], tex.numpy()[2:3]
-        entry, res = one_case(fv, tex, isz, opts, with_cull_check=name in ('C2', 'C3', 'C4'))
-        print(parity.fmt(name + '@%d' % isz, res), 'ok' if entry['accepted'] else 'REJECTED', flush=True)
+        entry = one_case(fv, tex, isz, opts, with_cull_check=name in ('C2', 'C3', 'C4'), n_jitter=14 if isz <= 256 else (6 if isz <= 512 else 4))
+        print(short(name + '@%d' % isz, entry), flush=True)
         out['full_size'][name] = dict(entry, image_size=isz, faces=int(fv.shape[1]))
-    keys = ('rgba', 'grad_faces', 'grad_textures', 'grad_faces_cond', 'grad_textures_cond')
     cases = list(out['matrix'].values()) + list(out['full_size'].values())
-    out['summary'] = dict(
-        cases=len(cases), accepted=sum(1 for c in cases if c['accepted']),
-        over_1e5={k: sum(1 for c in cases if c['hip_vs_oracle'][k]['max_rel'] > 1e-5) for k in keys},
-        over_1e5_p99={k: sum(1 for c in cases if c['hip_vs_oracle'][k]['p99_rel'] > 1e-5) for k in keys},
-        cull_identical=sum(1 for c in cases if c.get('cull_identical', True)))
+    summ = dict(cases=len(cases), cull_identical=sum(1 for c in cases if c.get('cull_identical', True)))
+    for v in VARIANTS:
+        es = [c['variants'][v] for c in cases]
+        summ[v] = dict(accepted=sum(1 for e in es if e['accepted']),
+                       grad_faces_cond_over_1e5_max=sum(1 for e in es if e['grad_faces_cond']['max_rel'] > 1e-5),
+                       grad_faces_cond_over_1e5_p99=sum(1 for e in es if e['grad_faces_cond']['p99_rel'] > 1e-5))
+    summ['default_vs_exact_grad_faces_max'] = max(c['default_vs_exact']['grad_faces']['max_rel'] for c in cases)
+    out['summary'] = summ
     os.makedirs('gpurun_out', exist_ok=True)
     path = 'gpurun_out/parity_%s.json' % tag
     json.dump(out, open(path, 'w'), indent=1)

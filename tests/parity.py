@@ -55,9 +55,14 @@ def run_hip(fv, tex, image_size, opts, grad=None, device='cuda:0', variant=None)
     return out
 
 
-def run_oracle(fv, tex, image_size, opts, grad=None, dtype=np.float32, threads=0):
+def run_oracle(fv, tex, image_size, opts, grad=None, dtype=np.float32, threads=0, threshold_scale=1.0):
+    """`threshold_scale`: sensitivity analysis (tests/criteria.py) -- the reference's two contribution thresholds
+    (D <= 1e-6, kernel.cu:784; d^2 >= dist_eps * tau, :769) moved by that factor."""
     o, extra = split_options(opts)
-    oo = oracle.make_opts(image_size=image_size, texel_mode=extra['texel_mode'], num_threads=threads, **o)
+    if threshold_scale != 1.0:
+        o = dict(o, dist_eps=max(1.0, o['dist_eps'] * (1.0 + (threshold_scale - 1.0) * 1e-2)))
+    oo = oracle.make_opts(image_size=image_size, texel_mode=extra['texel_mode'], num_threads=threads,
+                          prob_threshold_scale=threshold_scale, **o)
     fwd = oracle.forward(fv, tex, oo, background=extra['background'], dtype=dtype)
     out = dict(rgba=fwd['rgba'], aggrs_info=fwd['aggrs_info'], faces_info=fwd['faces_info'])
     if grad is not None:

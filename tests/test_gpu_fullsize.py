@@ -33,9 +33,9 @@ def test_one_full_frame_against_oracle(oracle_mod, native_lib, opts):
         assert np.array_equal(h['rgba'][:, 3], r['rgba'][:, 3])
         assert res['rgba']['max_rel'] <= 1e-5
         assert res['grad_faces_cond']['max_rel'] <= 1e-5 and res['grad_textures_cond']['max_rel'] <= 1e-5
-    else:
-        grad = np.random.RandomState(1).randn(1, 4, 256, 256).astype(np.float32)
-        assert not criteria.check(res, criteria.noise_floor(fv, tex, 256, opts, grad))
+    grad = np.random.RandomState(1).randn(1, 4, 256, 256).astype(np.float32)
+    bad, _, _ = criteria.check_case(fv, tex, 256, opts, h, grad, oracle_f32=r)
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("name,opts,isz", [('C4', C4, 512), ('C5', C5, 768)])
@@ -46,7 +46,7 @@ def test_large_frames_against_oracle(oracle_mod, native_lib, name, opts, isz):
     fv, tex = fv[1:2], tex[1:2]
     res, h, r = parity.compare(fv, tex, isz, opts)
     grad = np.random.RandomState(1).randn(1, 4, isz, isz).astype(np.float32)
-    bad = criteria.check(res, criteria.noise_floor(fv, tex, isz, opts, grad))
+    bad, _, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r, n_jitter=6)
     assert not bad, bad
 
 

@@ -33,8 +33,8 @@ def test_random_shape_and_option_set(oracle_mod, native_lib, seed):
     name, opts, fv, tex, isz = _draw(np.random.RandomState(1000 + seed))
     res, h, r = parity.compare(fv, tex, isz, opts)
     grad = np.random.RandomState(1).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
-    noise = criteria.noise_floor(fv, tex, isz, opts, grad, oracle_f32=r)
-    assert not criteria.check(res, noise), (name, fv.shape, isz, criteria.check(res, noise))
+    bad, _, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r)
+    assert not bad, (name, fv.shape, isz, bad)
     h2 = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
     for k in ('rgba', 'aggrs_info'):
         assert np.array_equal(h[k], h2[k], equal_nan=True), (name, k)

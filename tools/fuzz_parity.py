@@ -29,8 +29,7 @@ for case in range(n_cases):
     opts['T'] = T
     res, h, r = parity.compare(fv, tex, isz, opts)
     grad = np.random.RandomState(1).randn(B, 4, isz, isz).astype(np.float32)
-    noise = criteria.noise_floor(fv, tex, isz, opts, grad, oracle_f32=r)
-    fails = criteria.check(res, noise)
+    fails, _, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r)
     h2 = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
     same = all(np.array_equal(h[k], h2[k], equal_nan=True) for k in ('rgba', 'aggrs_info'))
     if not same:
