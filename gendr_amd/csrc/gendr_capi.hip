@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "gendr_kernels.h"
 #include "gendr_project.h"
@@ -201,7 +203,7 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
 }
 
 // Grid of a render kernel: a quarter of one-wave-per-tile (waves stride over their queue), but never fewer than 16384
-// waves while there are that many tiles -- small batches are bound by the longest wave, not by the number of waves
+// waves (or four per tile) -- small batches are bound by the longest wave, not by the number of waves
 // (measured at 256^2: batch 8 179 -> 136 us per step, batch 16 192 -> 154 us, batch 32 226 -> 208 us; batch 64 is the
 // quarter) -- and a multiple of 8 so that every XCD gets the same number of workgroups.
 #ifndef GENDR_GRID_DIV
@@ -213,10 +215,33 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
 int render_blocks(int total_blocks)
 {
     int blocks = (total_blocks + GENDR_GRID_DIV - 1) / GENDR_GRID_DIV;
-    const int floor_ = total_blocks < GENDR_GRID_MIN ? total_blocks : GENDR_GRID_MIN;
+    // up to four waves per tile below GENDR_GRID_MIN: the spare waves split the listed tiles by pixel rows (walk_split_log2)
+    const long four = 4L * total_blocks;
+    const int floor_ = four < GENDR_GRID_MIN ? (int)four : GENDR_GRID_MIN;
     if (blocks < floor_) blocks = floor_;
     if (blocks < 1) blocks = 1;
     return ((blocks + 7) / 8) * 8;
+}
+
+// Waves of a render kernel the chip holds at once, per tile queue: occupancy (one-wave workgroups per CU) x CUs / 8.
+// Queried once per kernel and device.
+int resident_per_queue(render_kernel_t k)
+{
+    struct Slot { render_kernel_t k; int dev; int v; };
+    static thread_local Slot cache[16];
+    static thread_local int used = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    for (int i = 0; i < used; i++)
+        if (cache[i].k == k && cache[i].dev == dev) return cache[i].v;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), kThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    (void)hipGetLastError();
+    const int v = per_cu * cus / 8;
+    if (getenv("GENDR_DEBUG")) fprintf(stderr, "gendr: resident_per_queue per_cu %d cus %d -> %d\n", per_cu, cus, v);
+    if (used < 16) cache[used++] = Slot{k, dev, v};
+    return v;
 }
 
 int check_launch()
@@ -411,6 +436,7 @@ int gendr_silhouette_forward(const float* faces, float* alpha, void* workspace, 
     a.iou_sums = iou_sums;
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm, true);
+    a.resident_q = resident_per_queue(k.fwd);
     hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
@@ -436,6 +462,7 @@ int gendr_silhouette_backward(const float* alpha, const void* workspace, const f
     a.grad_textures = grad_faces;            // never written: the alpha-only kernels have no texture term
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm, true);
+    a.resident_q = resident_per_queue(k.bwd);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
@@ -610,6 +637,7 @@ int gendr_forward(const float* faces, const float* textures, float* rgba, float*
     a.rgba = rgba;
     a.aux = aggrs_info;
     const KernelEntry& k = pick_kernel(p, texm);
+    a.resident_q = resident_per_queue(k.fwd);
     hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
@@ -635,6 +663,7 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.grad_textures = grad_textures;
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm);
+    a.resident_q = resident_per_queue(k.bwd);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }

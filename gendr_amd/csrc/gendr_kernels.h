@@ -247,6 +247,7 @@ struct RenderArgs {
     long          ent_cap8;     // capacity of one region of the entry pool
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
+    int resident_q;             // waves of the launched render kernel the chip holds at once, per tile queue (sub-tile split)
     gendr_params p;
     float thr;                  // dist_eps * dist_scale (kernel.cu:725)
     float softmax_sum0;         // exp(aggr_rgb_eps / aggr_rgb_gamma) (kernel.cu:729)
@@ -782,7 +783,32 @@ struct TileCtx {
 // The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
 // own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
 // tiles list a face) that is one tile per wave and no wave is launched in vain.
-struct TileWalk { long qbase, qend; int total, empties, rank, next, stride; };
+struct TileWalk { long qbase, qend; int total, empties, rank, next, stride, split_log2; };
+
+// Sub-tile split of the render kernels.  The latency of a launch is the latency of one wave on the heaviest tile (ten
+// batches at the headline scene); when a queue lists fewer tiles than the chip holds waves for it at once (resident_q, from
+// the occupancy of the kernel) -- small batches: the per-GPU share of a strong-scaling run -- every listed tile is rendered
+// by 2, 4 or 8 waves, each taking 4, 2 or 1 of its 8 pixel rows (more work items than resident waves only adds a second
+// generation of waves: measured at batch 16 and 32, slower).  A wave
+// keeps only the bits of its rows in the coverage masks, so its pair list, its batches and its time shrink by the split
+// (the entries are read once per wave, which is cheap; forward keeps every pixel's ascending face order, since a pixel
+// belongs to exactly one wave).
+#ifndef GENDR_SPLIT_MAX_LOG2
+#define GENDR_SPLIT_MAX_LOG2 3
+#endif
+__device__ __forceinline__ int walk_split_log2(const TileWalk& w, int resident_q)
+{
+    int s = 0;
+    while (s < GENDR_SPLIT_MAX_LOG2 && ((long)w.total << (s + 1)) <= (long)min(w.stride, resident_q + (resident_q >> 2))) s++;
+    return s;
+}
+// pixel lanes (bits) of sub-tile `sub` of 1 << split_log2: whole rows of 8 pixels
+__device__ __forceinline__ unsigned long long sub_tile_mask(int split_log2, int sub)
+{
+    if (split_log2 == 0) return ~0ull;
+    const int bits = 64 >> split_log2;
+    return ((1ull << bits) - 1ull) << (sub * bits);
+}
 
 __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int waves_per_block)
 {
@@ -794,6 +820,7 @@ __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int 
     w.stride = (int)(gridDim.x >> 3) * waves_per_block;
     w.rank = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * waves_per_block + (int)(threadIdx.x >> 6));
     w.next = w.rank;
+    w.split_log2 = 0;
 }
 
 __device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int tile)
@@ -1308,6 +1335,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
 //     tables and split decisions: ~45 instructions per entry, and per tile that was as much as a batch of pair math);
 //   * entries are appended until at least kFillCodes are listed; the full batches run -- from ONE call site, so that the
 //     caller's phase B is compiled once -- and the remainder (< 64 codes) moves to the front of the buffer;
+//   * `pixels` restricts the list to the pixel rows this wave renders (sub-tile split, see walk_split_log2);
 //   * a tile without a slice of the entry pool (off < 0) produces its entries here instead, up to 64 at a time: its mask
 //     row is walked with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact per-pixel
 //     tests (collect_pairs) -- same entries, only slower.
@@ -1315,7 +1343,7 @@ constexpr int kChunkBatches = 4;
 constexpr int kFillCodes = kChunkBatches * 64, kCodeCap = kFillCodes + 64;
 
 template <int REC, typename Body>
-__device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCtx& t, int off, int cnt, int* s_code, Body body)
+__device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCtx& t, int off, int cnt, unsigned long long pixels, int* s_code, Body body)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1372,7 +1400,8 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
                 if (n <= 0) { done = true; break; }
             }
             const int fn = __builtin_amdgcn_readlane(e.x, j);
-            const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j);
+            const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j))
+                                         & pixels;              // this wave's rows of the tile, see sub_tile_mask
             j++;
             if ((m >> lane) & 1ull) s_code[npairs + __popcll(m & lt)] = (fn << 6) | lane;
             npairs += __popcll(m);
@@ -1488,12 +1517,15 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     }
 #endif
 
-    for (; tw.next < tw.total; tw.next += tw.stride) {
+    tw.split_log2 = walk_split_log2(tw, a.resident_q);
+    for (; tw.next < (tw.total << tw.split_log2); tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries, pairs): scalar load
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
+    const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
     TileCtx t;
     tile_setup(t, a, ti.x);
+    t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels this wave renders
 
     s_xy[wave][lane] = make_float2(t.xp, t.yp);
 
@@ -1608,7 +1640,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         __builtin_amdgcn_wave_barrier();
     };
 
-    for_each_batch<REC>(a, t, ti.y, ti.z, s_code[wave], run_batch);
+    for_each_batch<REC>(a, t, ti.y, ti.z, my_rows, s_code[wave], run_batch);
 
     if constexpr (kSil) {
         // alpha plane, and the tile's share of the fused IoU sums (opt_shape.py:20-24: intersect = sum(a t),
@@ -1721,12 +1753,15 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     walk_init(tw, a, WAVES);
     GENDR_T(0);                                   // 0: wave start-up (queue lengths)
     GENDR_STAMP(1);
-    for (; tw.next < tw.total; tw.next += tw.stride) {
+    tw.split_log2 = walk_split_log2(tw, a.resident_q);
+    for (; tw.next < (tw.total << tw.split_log2); tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + tw.next));   // (tile, first entry, entries, pairs): scalar load
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
+    const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
     TileCtx t;
     tile_setup(t, a, ti.x);
+    t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels whose pairs this wave differentiates
     {
         PixIn pi;
 #pragma unroll
@@ -1991,7 +2026,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         GENDR_T(6);                               // 6: segment sums + atomics issued
     };
 
-    for_each_batch<REC>(a, t, ti.y, ti.z, s_code[wave], run_batch);
+    for_each_batch<REC>(a, t, ti.y, ti.z, my_rows, s_code[wave], run_batch);
     __builtin_amdgcn_wave_barrier();
     GENDR_T(7);                                   // 7: tail of the tile (entry walk after the last batch)
     }   // tile loop
