@@ -109,7 +109,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" float gendr_cull_radius(const gendr_params* p);
 
 struct Workspace {
-    size_t boxes_off, records_off, lists_off, tileinfo_off, entries_off, sorted_off, control_off, total;
+    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, sorted_off, control_off, total;
     bool ordered;              // the render kernels walk the heavy-first copy of the queue records (order_tiles_kernel)
     int tiles_x, chunks, supers_x, ncontrol;
     long ent_cap8;
@@ -142,7 +142,7 @@ long entry_capacity(long B, long tiles, long nf, const gendr_params* p)
     return ((long)want + 7) / 8 * 8;
 }
 
-// workspace layout: [bin records B*nf*16 f32][face records B*nf*REC f32]
+// workspace layout: [bin records B*nf*16 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
 //                   [tile queues B*tiles i32][queue records B*tiles 4 x i32][entry pool]
 //                   [heavy-first copy of the queue records, up to kOrderTilesMax tiles][control counters]
 Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
@@ -156,11 +156,13 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.ent_cap8 = entry_capacity(B, (long)w.tiles_x * w.tiles_x, nf, p) / 8;
     w.boxes_off = 0;
     w.records_off = align256((size_t)B * nf * kBinRec * sizeof(float));
-    w.lists_off = w.records_off + align256((size_t)B * nf * record_floats(texm) * sizeof(float));
+    w.masks_off = w.records_off + align256((size_t)B * nf * record_floats(texm) * sizeof(float));
+    // tile masks (binning -> coverage): not needed when there is no entry pool -- the coverage kernel then has nothing to do
+    w.lists_off = w.masks_off + (w.ent_cap8 > 0 ? align256(tiles * w.chunks * sizeof(unsigned long long)) : 0);
     w.tileinfo_off = w.lists_off + align256(tiles * sizeof(int));
     w.entries_off = w.tileinfo_off + align256(tiles * sizeof(int4));
     w.sorted_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
-    w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16;
+    w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16 && w.ent_cap8 > 0;   // (no pool: no pair counts to order by)
     w.control_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
     w.ncontrol = kCtlInts;
     w.total = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
@@ -173,6 +175,7 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     const Workspace w = workspace_layout(B, nf, T, p);
     memset(&a, 0, sizeof(a));
     a.records = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + w.records_off);
+    a.masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + w.masks_off);
     a.tile_list = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.lists_off);
     a.control = reinterpret_cast<int*>(static_cast<char*>(const_cast<void*>(workspace)) + w.control_off);
     a.tile_info_raw = reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.tileinfo_off);
@@ -565,7 +568,7 @@ int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* 
     return check_launch();
 }
 
-// face records + cull boxes, tile queues, coverage entries
+// face records + cull boxes, tile masks, tile queues, coverage entries
 int gendr_face_setup(const float* faces, const float* textures, void* workspace,
                      int B, int nf, int T, const gendr_params* p, void* stream)
 {
@@ -596,12 +599,23 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
         hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, clear4, clear_quads);
     int e = check_launch();
     if (e != GENDR_OK) return e;
-    // one workgroup per (image, 64x64 super-tile): tile queues and the coverage entries of the listed tiles
+    // one workgroup per (image, 64x64 super-tile): tile masks and the tile queues
     RenderArgs a;
     fill_args(a, workspace, textures, B, nf, T, p);
     const long bblocks = (long)B * w.supers_x * w.supers_x;
     if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
-    hipLaunchKernelGGL(tile_cover_kernel, dim3((unsigned)bblocks), dim3(kCoverThreads), 0, s, boxes, a, w.supers_x, p->cull);
+    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kBinThreads), 0, s, boxes, a, w.supers_x, p->cull);
+    e = check_launch();
+    if (e != GENDR_OK) return e;
+    // coverage entries of the listed tiles: one wave per queue slot, same walk as the render kernels
+#ifndef GENDR_COVER_GRID_MUL
+#define GENDR_COVER_GRID_MUL 1
+#endif
+    if (w.ent_cap8 == 0) return GENDR_OK;                       // no entry pool: every listed tile takes the render kernels' own walk
+    const int cblocks = render_blocks(a.total_blocks) * GENDR_COVER_GRID_MUL;
+    if (texm == kTexSurface1)    hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurface1)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+    else if (texm == kTexVertex) hipLaunchKernelGGL(cover_kernel<record_floats(kTexVertex)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+    else                         hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurfaceN)>, dim3(cblocks), dim3(kThreads), 0, s, a);
     e = check_launch();
     if (e != GENDR_OK) return e;
     // heavy tiles first: the render kernels walk the sorted copy of the queue records

@@ -3,7 +3,7 @@
 // Replaces the three __global__ kernels of the reference
 // (gendr/cuda/generalized_renderer_cuda_kernel.cu = "kernel.cu"):
 //   forward_render_inv_cuda_kernel :620-676  ->  face_setup_kernel (+ face_info_kernel, reference layout)
-//                                                tile_cover_kernel (new: exact tile culling + per-pixel coverage)
+//                                                bin_faces_kernel + cover_kernel (new: exact tile culling, per-pixel coverage)
 //   forward_render_cuda_kernel     :680-862  ->  render_forward_kernel
 //   backward_render_cuda_kernel    :866-1065 ->  render_backward_kernel
 //
@@ -185,7 +185,7 @@ constexpr int kSplitMin = GENDR_SPLIT_MIN;   // a face's pairs are split over tw
 // the 8 XCDs, so the waves of workgroups with blockIdx.x & 7 == x walk queue x: the tiles of an image (band) are
 // rendered through one XCD's L2, which then holds that image's face records and mask rows once.  (If the dispatch
 // order were different every tile would still be rendered exactly once; only the locality would suffer.)
-//   [(16 + x) * kCtlStride]        : entries allocated so far in region x of the entry pool (tile_cover_kernel; 64-bit).
+//   [(16 + x) * kCtlStride]        : entries allocated so far in region x of the entry pool (bin_faces_kernel; 64-bit).
 constexpr int kCtlStride = 1024, kCtlInts = 24 * kCtlStride;
 
 // Per-face record of the binning kernel (floats): the cull box, then for each edge k the row (a, b, c) of the
@@ -193,7 +193,7 @@ constexpr int kCtlStride = 1024, kCtlInts = 24 * kCtlStride;
 constexpr int kBinRec = 16;
 
 // One entry of a tile's coverage list: face index and the ballot of the tile's pixels that pass the exact box / edge
-// tests for it (bit p = pixel lane p).  Written by tile_cover_kernel, read by both render kernels.
+// tests for it (bit p = pixel lane p).  Written by cover_kernel, read by both render kernels.
 struct __attribute__((aligned(16))) CoverEnt { int fn; int npix; unsigned lo, hi; };
 
 __device__ __forceinline__ long queue_begin(int x, long n_tiles) { return ((long)x * n_tiles) >> 3; }
@@ -202,6 +202,7 @@ __device__ __forceinline__ int queue_of_tile(long g, long n_tiles) { return (int
 
 struct RenderArgs {
     const float*  records;      // [B*nf][REC]
+    const unsigned long long* masks;   // [B*tiles][chunks] : bit f of chunk c set = face 64c+f may touch the tile (binning -> coverage)
     const float*  textures;     // [B,nf,T,3]
     float*        rgba;         // [B,4,is,is]
     float*        aux;          // [B,2,is,is]
@@ -215,12 +216,12 @@ struct RenderArgs {
     int*          tile_list;    // [B * tiles_per_image]: 8 queues of global tile ids, see kCtlInts
     int*          control;      // queue lengths
     CoverEnt*     entries;      // entry pool: 8 regions of ent_cap8 entries (one per tile queue)
-    int4*         tile_info_raw;// the queue records in the order tile_cover_kernel appended them
+    int4*         tile_info_raw;// the queue records in the order the binning kernel appended them (written by it and cover_kernel)
     int4*         tile_info;    // what the render kernels walk: the heavy-first copy of order_tiles_kernel, or tile_info_raw
                                 // [B * tiles_per_image], parallel to tile_list: (tile, first entry, entries, pairs) of the queue
                                 //   slot -- tile, first entry (-1: pool exhausted, the render
                                 //   kernels then run the per-pixel tests themselves from the mask row), the entry count
-                                //   pair count from tile_cover_kernel: one scalar load tells a wave all it needs
+                                //   pair count from cover_kernel: one scalar load tells a wave all it needs
     long          ent_cap8;     // capacity of one region of the entry pool
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
@@ -502,7 +503,30 @@ __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry
     return !(rx_lo > box.y || rx_hi < box.x || ry_lo > box.w || ry_hi < box.z);
 }
 
+#ifndef GENDR_BIN_LOOP_MAX
+#define GENDR_BIN_LOOP_MAX 16
+#endif
+#ifndef GENDR_BIN_THREADS
+#define GENDR_BIN_THREADS 512
+#endif
+// ---------------------------------------------------------------------------------------------
+// binning: masks[b][tile][chunk], bit f of chunk c = face 64c+f of image b may touch the 8x8 tile; and the tile
+// queues the render kernels walk.
+// One workgroup takes a block of 8x8 tiles (a 64x64 pixel super-tile) of one image; its wavefronts share the face
+// chunks.  For a chunk, lane = face (coalesced box load) and lane = tile as well: a ballot finds the few faces whose
+// box meets the super-tile at all; for each of them the box is broadcast with v_readlane and every tile lane sets
+// its bit.  The words go to LDS, from where the mask rows leave in runs of 8 tiles x chunks words (the rows of 8
+// horizontally adjacent tiles are contiguous in HBM).  Once all chunks are done the first wavefront knows, per tile,
+// whether its row is empty and appends the tile to its queue: listed tiles grow the queue from the front, the others
+// -- the background, three quarters of the headline scene -- from the back of the queue's slots (the forward kernel
+// writes their pixels in a store-only loop, backward never looks at them).  Two atomics per workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBinThreads = GENDR_BIN_THREADS, kBinWaves = kBinThreads / 64;
+constexpr int kBinGroup = 32;      // chunks staged in LDS per round
+constexpr int kBinLoopMax = GENDR_BIN_LOOP_MAX;   // up to this many candidate faces of a chunk are broadcast one by one
+
 __device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float4 bcast4(const float4& v, int l) { return make_float4(bcast(v.x, l), bcast(v.y, l), bcast(v.z, l), bcast(v.w, l)); }
 
 __device__ __forceinline__ int wave_exclusive_scan(int v, int& total)
 {
@@ -517,54 +541,19 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int& total)
     return incl - v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// tile coverage: binning and per-pixel coverage in ONE launch (round 3; replaces bin_faces_kernel + cover_kernel and the
-// tile-mask array between them)
-//
-// One workgroup (8 wavefronts) per (image, 64x64-pixel super-tile), handed out from the image centre outwards.
-//   1 candidates  lane = face: the faces whose cull box meets the super-tile at all are compacted, in ascending order, into
-//                 LDS together with their 64-byte bin records (box + the three barycentric rows with their edge-cull
-//                 thresholds: everything the per-pixel coverage test needs) -- up to kCandCap per round;
-//   2 tile masks  lane = candidate: one bit per (tile, candidate) by the separable box test, in LDS only;
-//   3 queues      the first wavefront counts the listings of every tile, queues the tiles (listed ones from the front with
-//                 a slice of the entry pool sized for their listings, unlisted ones from the back, an empty super-tile as
-//                 one entry) -- three atomics per workgroup on counters 4 KiB apart;
-//   4 coverage    the wavefronts take the listed tiles one by one (LDS ticket): eight candidates per step, lane = (candidate,
-//                 pixel row), the records come from LDS -- no gather from L2 in the loop, which was what the separate
-//                 coverage kernel waited on -- the barycentrics of a row are stepped from its first pixel, and the faces
-//                 that own at least one pixel are appended, in ascending order, to the tile's slice of the entry pool.
-// Meshes whose super-tile window holds more than kCandCap faces take several rounds: a counting sweep over all rounds
-// (steps 1-2, listings only), the allocation, and a second sweep that stages every round again and emits its entries
-// behind the previous round's.  With one round (the usual case) the staged round is used directly.
-// ---------------------------------------------------------------------------------------------
-constexpr int kCoverThreads = 512, kCoverWaves = kCoverThreads / 64;
-constexpr int kCandCap = 512;                 // candidates staged per round: 32 KB of bin records
-constexpr int kCandWords = kCandCap / 64;
-constexpr int kListCap = 128;                 // candidates of one tile unpacked per pass (>= 64: one mask word must fit)
-
-__device__ __forceinline__ unsigned quad_or(unsigned v)
+__global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
 {
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    return v;
-}
-
-__global__ __launch_bounds__(kCoverThreads) void tile_cover_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
-{
-    __shared__ __attribute__((aligned(16))) float4 s_rec[kCandCap][4];     // bin records of the round's candidates
-    __shared__ int s_cand[kCandCap];                                       // their face indices (ascending)
-    __shared__ unsigned long long s_tmask[64][kCandWords];                 // bit c of row t: candidate c's box meets tile t
-    __shared__ int s_flist[kCoverWaves][kListCap];                         // a tile's candidates, unpacked (per wavefront)
-    __shared__ int s_cnt[kCoverWaves];                                     // candidates found by each wavefront in a group of chunks
-    __shared__ int s_listings[64], s_off[64], s_slot[64], s_nout[64], s_pairs[64];
-    __shared__ int s_ticket, s_empty_super;
-
+    __shared__ unsigned long long s_words[64][kBinGroup + 1];
+    __shared__ int s_listed[64];
+    GENDR_SPAN_BEGIN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int is = a.is, tiles_x = a.tiles_x;
+    const int is = a.is, tiles_x = a.tiles_x, chunks = a.chunks;
     const int per_image = supers_x * supers_x;
-    // centre-out order of the super-tiles, all images' first ring first (workgroups start in index order over a dispatch
-    // ramp, and the ones under the object live longest)
+    // Workgroups start in index order and the ones under the object live four times as long as the ones over the
+    // background (16 against 4 us at C2), so the super-tiles are handed out from the image centre outwards, ring by
+    // ring, all images' first ring first: where the object is roughly centred the long workgroups start first instead
+    // of somewhere in a 10-us dispatch ramp; where it is not, the order is as good as any other.
     const int nimg = (int)(gridDim.x / per_image);
     const int b = blockIdx.x % nimg;
     int sy, sx;
@@ -580,7 +569,7 @@ __global__ __launch_bounds__(kCoverThreads) void tile_cover_kernel(const float* 
         else                      { sy = o + 1 + pos - (3 * n - 2); sx = o + n - 1; }     // right column
     }
 
-    // lane t also stands for tile t of the super-tile: its rectangle of pixel centres
+    // lane t owns tile t of the super-tile: its rectangle and, at the end, its mask words
     const int ty_l = sy * 8 + (lane >> 3), tx_l = sx * 8 + (lane & 7);
     const bool tile_ok = ty_l < tiles_x && tx_l < tiles_x;
     const float rx_lo = pixel_coord(tx_l * 8, is, a.r_is), rx_hi = pixel_coord(min(tx_l * 8 + 7, is - 1), is, a.r_is);
@@ -588,50 +577,34 @@ __global__ __launch_bounds__(kCoverThreads) void tile_cover_kernel(const float* 
     const float sx_lo = pixel_coord(sx * 64, is, a.r_is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is, a.r_is);
     const float sy_hi = pixel_coord(is - 1 - sy * 64, is, a.r_is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is, a.r_is);
     const long tile_base = (long)b * a.tiles_per_image;
-    const float4* recs4 = reinterpret_cast<const float4*>(boxes) + (long)b * a.nf * (kBinRec / 4);
-    const int ngroups = (a.chunks + kCoverWaves - 1) / kCoverWaves;      // a group = one 64-face chunk per wavefront
+    int listed_faces = 0;                                                    // first wavefront: faces listed for this lane's tile
 
-    if (threadIdx.x < 64) { s_listings[threadIdx.x] = 0; s_nout[threadIdx.x] = 0; s_pairs[threadIdx.x] = 0; s_off[threadIdx.x] = -1; s_slot[threadIdx.x] = -1; }
-    if (threadIdx.x == 0) { s_ticket = 0; s_empty_super = 0; }
-
-    int g = 0;                     // next group of chunks to stage (uniform)
-    int ncand = 0;                 // candidates of the staged round
-
-    // ---- steps 1 + 2 for the round that starts at group g: candidates -> LDS, tile masks -> LDS
-    auto stage_round = [&]() __attribute__((always_inline)) {
-        ncand = 0;
-        __syncthreads();                                                 // the previous round's readers are done
-        while (g < ngroups) {
-            const int fi = (g * kCoverWaves + wave) * 64 + lane;
-            const bool have = fi < a.nf;
-            float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
-            if (have) box = recs4[(long)fi * 4];
-            const unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
-            if (lane == 0) s_cnt[wave] = __popcll(cand);
-            __syncthreads();
-            int before = 0, total = 0;
+    for (int c0 = 0; c0 < chunks; c0 += kBinGroup) {
+        const int ng = min(kBinGroup, chunks - c0);
+        constexpr int kPerWave = (kBinGroup + kBinWaves - 1) / kBinWaves;
 #pragma unroll
-            for (int w = 0; w < kCoverWaves; w++) { const int c = s_cnt[w]; if (w < wave) before += c; total += c; }
-            if (ncand + total > kCandCap) { __syncthreads(); break; }    // the group opens the next round (total <= 512 always fits an empty round)
-            if ((cand >> lane) & 1ull) {
-                const int at = ncand + before + __popcll(cand & lt);
-                s_cand[at] = fi;
-                s_rec[at][0] = box;
-                s_rec[at][1] = recs4[(long)fi * 4 + 1];
-                s_rec[at][2] = recs4[(long)fi * 4 + 2];
-                s_rec[at][3] = recs4[(long)fi * 4 + 3];
-            }
-            ncand += total;
-            g++;
-            __syncthreads();                                             // s_cnt is rewritten by the next group
-        }
-        // tile masks: wavefront w takes candidate words w, w + 8, ...; lane = candidate
-        const int nwords = (ncand + 63) >> 6;
-        for (int w = wave; w < kCandWords; w += kCoverWaves) {
+        for (int u = 0; u < kPerWave; u++) {
+            const int ci = wave + u * kBinWaves;
+            if (ci >= ng) break;
+            const int fi = (c0 + ci) * 64 + lane;
+            const bool have = fi < a.nf;
+            float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
+            if (have) box = (reinterpret_cast<const float4*>(boxes) + ((long)b * a.nf + fi) * (kBinRec / 4))[0];
             unsigned long long mine = 0ull;
-            if (w < nwords) {
-                const int c = w * 64 + lane;
-                const float4 box = c < ncand ? s_rec[c][0] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+            // Box test only (measured in round 2: an exact per-(face, tile) edge test removes a third of the listings but
+            // costs this kernel 43 us at C2; the coverage kernel drops those faces for 10 us).
+            unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
+            if (__popcll(cand) <= kBinLoopMax) {
+                // a handful: broadcast each box, every tile lane sets its bit
+                while (cand) {
+                    const int l = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    const float4 fb = bcast4(box, l);
+                    if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << l;
+                }
+            } else {
+                // many (the super-tiles under the object): the same predicate is separable, so every face lane marks
+                // the tile columns and tile rows its box meets and one ballot per tile collects that tile's word
                 unsigned mx = 0u, my = 0u;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -642,203 +615,93 @@ __global__ __launch_bounds__(kCoverThreads) void tile_cover_kernel(const float* 
                     mx |= (hx ? 1u : 0u) << k;
                     my |= (hy ? 1u : 0u) << k;
                 }
-                if (c >= ncand) mx = 0u;
+                if (!((cand >> lane) & 1ull)) mx = 0u;              // also drops lanes without a face
 #pragma unroll
                 for (int tl = 0; tl < 64; tl++) {
                     const unsigned long long word = __ballot(((mx >> (tl & 7)) & 1u) && ((my >> (tl >> 3)) & 1u));
                     if (lane == tl) mine = word;
                 }
-                if (!tile_ok) mine = 0ull;
             }
-            s_tmask[lane][w] = mine;
+            s_words[lane][ci] = mine;
         }
         __syncthreads();
-    };
-
-    // ---- sweep 1: listings per tile over all rounds
-    bool single = false;
-    for (;;) {
-        const int g0 = g;
-        stage_round();
         if (wave == 0) {
-            int n = 0;
-#pragma unroll
-            for (int w = 0; w < kCandWords; w++) n += __popcll(s_tmask[lane][w]);
-            s_listings[lane] += n;
+            for (int ci = 0; ci < ng; ci++) listed_faces += __popcll(s_words[lane][ci]);
+            s_listed[lane] = listed_faces != 0;
         }
-        if (g >= ngroups) { single = g0 == 0; break; }
-    }
-    __syncthreads();
-
-    // ---- step 3: tile queues and the tiles' slices of the entry pool (first wavefront; usually the 64 tiles belong to one
-    // queue, small batches of small images put several into one wave)
-    if (wave == 0) {
-        int listed_faces = tile_ok ? s_listings[lane] : 0;
-        const long gt = tile_base + (long)ty_l * tiles_x + tx_l;
-        const int xq = tile_ok ? queue_of_tile(gt, a.total_tiles) : -1;
-        bool whole_empty = false;
-        // A super-tile that lies wholly inside the image and lists nothing anywhere becomes ONE entry of the unlisted
-        // queue, -(its first tile) - 1: the forward kernel fills its 64 x 64 pixels with 256-byte row segments instead of
-        // 64 tiles' 32-byte ones (image rows of a multiple of four pixels, for 16-byte stores).
-        if ((is & 3) == 0 && sx * 64 + 64 <= is && sy * 64 + 64 <= is) {
-            const int x0 = __builtin_amdgcn_readlane(xq, 0);
-            if (__ballot(listed_faces == 0 && xq == x0) == ~0ull) {
-                whole_empty = true;
-                if (lane == 0) {
-                    const int base_e = atomicAdd(a.control + (8 + x0) * kCtlStride, 1);
-                    a.tile_list[queue_begin(x0 + 1, a.total_tiles) - 1 - base_e] = -(int)gt - 1;
-                    s_empty_super = 1;
-                }
-            }
-        }
-        unsigned long long todo = whole_empty ? 0ull : __ballot(tile_ok);
-        while (todo) {
-            const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
-            const unsigned long long mine = __ballot(xq == x);
-            todo &= ~mine;
-            const unsigned long long listed = __ballot(xq == x && listed_faces != 0);
-            const unsigned long long empty = mine & ~listed;
-            int need = 0;
-            const int before = wave_exclusive_scan(xq == x ? listed_faces : 0, need);
-            int base_l = 0, base_e = 0;
-            long base_n = 0;
-            if (lane == 0) {
-                if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
-                if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
-                // entries handed out so far in region x of the pool: 64-bit, so that requests beyond the pool (heavy-tailed
-                // distributions list every face in every tile) cannot wrap the counter; an exhausted region is not advanced
-                if (need) {
-                    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.control + (16 + x) * kCtlStride);
-                    base_n = (long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    base_n = base_n + need <= a.ent_cap8 ? (long)atomicAdd(ctr, (unsigned long long)need) : a.ent_cap8;
-                }
-            }
-            base_l = __builtin_amdgcn_readfirstlane(base_l);
-            base_e = __builtin_amdgcn_readfirstlane(base_e);
-            base_n = ((long)__builtin_amdgcn_readfirstlane((int)(base_n >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base_n);
-            if ((listed >> lane) & 1ull) {
-                const long slot = queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt);
-                const long at = base_n + before;                                    // inside region x of the pool
-                const bool fits = at >= 0 && at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL;
-                const int off = fits ? (int)((long)x * a.ent_cap8 + at) : -1;
-                a.tile_list[slot] = (int)gt;
-                s_off[lane] = off;
-                s_slot[lane] = (int)(slot - queue_begin(0, a.total_tiles));         // queue slots fit an int (gendr_validate)
-                if (off < 0) a.tile_info_raw[slot] = make_int4((int)gt, -1, 0, 0);  // no room: the render kernels test this tile themselves
-            }
-            if ((empty >> lane) & 1ull) a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)gt;
-        }
-    }
-    __syncthreads();
-    if (s_empty_super || a.ent_cap8 == 0) return;      // nothing listed here / no entry pool for this option set (see entry_capacity)
-
-    // ---- step 4 (sweep 2): coverage of the listed tiles, round by round
-    if (!single) g = 0;
-    for (;;) {
-        if (!single) {
-            stage_round();
-            if (threadIdx.x == 0) s_ticket = 0;
-            __syncthreads();
-        }
-        const int nwords = (ncand + 63) >> 6;
-        for (;;) {
-            int tl = 0;
-            if (lane == 0) tl = atomicAdd(&s_ticket, 1);
-            tl = __builtin_amdgcn_readfirstlane(tl);
-            if (tl >= 64) break;
-            const int off = s_off[tl];
-            if (off < 0) continue;                       // unlisted, outside the image, or no room in the pool
-            // ---- one tile: lane = (candidate slot, pixel row)
-            const int slot = lane >> 3, prow = lane & 7;
+        // Nobody reads the mask row of a tile that lists no face (such a tile is not queued), so when the whole row is
+        // known here -- one group holds all chunks, up to 2048 faces -- the rows of empty tiles are not written at all
+        // (the background: 79 % of the tiles of BASELINE config 5, 265 MB of zeros per call at batch 32).
+        const bool skip_empty = chunks <= kBinGroup;
+        if (skip_empty) __syncthreads();
+        // (no entry pool for this option set, see entry_capacity: nobody reads the masks, and they have no buffer)
+        for (int idx = threadIdx.x; idx < (a.ent_cap8 > 0 ? 64 * ng : 0); idx += kBinThreads) {   // consecutive threads: consecutive words of a row
+            const int tl = idx / ng, ci = idx - tl * ng;
             const int ty = sy * 8 + (tl >> 3), tx = sx * 8 + (tl & 7);
-            const int x0 = tx * kTile, row_a = ty * kTile + prow;
-            const bool row_ok = row_a < is;
-            const float yp_a = pixel_coord(is - 1 - row_a, is, a.r_is);
-            float xs[8];                               // pixel centres of the tile's columns, and the nominal pixel pitch
-#pragma unroll
-            for (int c = 0; c < 8; c++) xs[c] = pixel_coord(x0 + c, is, a.r_is);
-            const float pitch = (float)(2. * a.r_is);
-            CoverEnt* out = a.entries + off + s_nout[tl];
-            int nout = 0, my_pairs = 0;
-
-            unsigned long long wv = lane < nwords ? s_tmask[tl][lane] : 0ull;
-            unsigned long long nz = __ballot(wv != 0ull);
-            while (nz) {
-                // ---- unpack up to kListCap candidates of the tile
-                int nlist = 0;
-                while (nz) {
-                    const int j = __builtin_ctzll(nz);
-                    const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), j) << 32)
-                                               | (unsigned)__builtin_amdgcn_readlane((int)wv, j);
-                    const int cnt = __popcll(w);
-                    if (nlist + cnt > kListCap) break;                       // the word stays in nz for the next pass
-                    nz &= nz - 1;
-                    if ((w >> lane) & 1ull) s_flist[wave][nlist + __popcll(w & lt)] = j * 64 + lane;
-                    nlist += cnt;
-                }
-                __builtin_amdgcn_wave_barrier();
-                // ---- eight candidates per step
-                for (int i0 = 0; i0 < nlist; i0 += 8) {
-                    const bool has = i0 + slot < nlist;
-                    const int c = s_flist[wave][has ? i0 + slot : i0];
-                    const float4 box = s_rec[c][0], e0 = s_rec[c][1], e1 = s_rec[c][2], e2 = s_rec[c][3];
-                    unsigned m8 = 0u;
-                    // The entries only have to be a superset of the contributing pairs (every pair still meets the reference's
-                    // own skip tests in the render kernels), so the barycentrics of a row are stepped from its first pixel
-                    // instead of being evaluated eight times: w += a * pitch.  Against the expression the edge thresholds were
-                    // derived for (barycentrics(), three roundings) the stepped value is off by at most 17 roundings of
-                    // magnitudes below |a| + |b| + |c| (|x|, |y| <= 1) = 1.06 * 2^-20 of that sum: the thresholds are lowered
-                    // by 2^-19 of it -- about 2e-4 pixel -- and a pixel is dropped only below them.  NaN and infinite
-                    // coefficients drop nothing (their threshold is -inf, see face_setup_kernel).
-                    if (has && row_ok && !(yp_a > box.w || yp_a < box.z)) {
-                        constexpr float kSlack = 1.9073486328125e-06f;                      // 2^-19
-                        float w0 = e0.x * xs[0] + e0.y * yp_a + e0.z;
-                        float w1 = e1.x * xs[0] + e1.y * yp_a + e1.z;
-                        float w2 = e2.x * xs[0] + e2.y * yp_a + e2.z;
-                        const float t0 = e0.w - kSlack * (fabsf(e0.x) + fabsf(e0.y) + fabsf(e0.z));
-                        const float t1 = e1.w - kSlack * (fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z));
-                        const float t2 = e2.w - kSlack * (fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z));
-                        const float d0 = e0.x * pitch, d1 = e1.x * pitch, d2 = e2.x * pitch;
-#pragma unroll
-                        for (int cc = 0; cc < 8; cc++) {
-                            const bool live = x0 + cc < is && !(xs[cc] > box.y || xs[cc] < box.x) && !(w0 < t0 || w1 < t1 || w2 < t2);
-                            m8 |= (live ? 1u : 0u) << cc;
-                            w0 += d0; w1 += d1; w2 += d2;
-                        }
-                    }
-                    my_pairs += __popc(m8);
-                    const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
-                    const unsigned hi = (unsigned)__shfl_down((int)v, 4);                  // lane 8s reads lane 8s+4 (rows 4-7)
-                    const bool owns = prow == 0 && (v | hi) != 0u;
-                    const unsigned long long keep = __ballot(owns);
-                    if (owns) {
-                        CoverEnt e;
-                        e.fn = s_cand[c]; e.npix = __popc(v) + __popc(hi); e.lo = v; e.hi = hi;
-                        out[nout + __popcll(keep & lt)] = e;
-                    }
-                    nout += __popcll(keep);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            // the tile's (pixel, face) pairs = its weight for order_tiles_kernel: summed across the lanes into lane 63
-#define GENDR_DPP_IADD(v, ctrl, rows) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xF, false))
-            my_pairs = GENDR_DPP_IADD(my_pairs, 0x111, 0xF);      // row_shr:1
-            my_pairs = GENDR_DPP_IADD(my_pairs, 0x112, 0xF);      // row_shr:2
-            my_pairs = GENDR_DPP_IADD(my_pairs, 0x114, 0xF);      // row_shr:4
-            my_pairs = GENDR_DPP_IADD(my_pairs, 0x118, 0xF);      // row_shr:8
-            my_pairs = GENDR_DPP_IADD(my_pairs, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
-            my_pairs = GENDR_DPP_IADD(my_pairs, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
-#undef GENDR_DPP_IADD
-            if (lane == 63) { s_nout[tl] += nout; s_pairs[tl] += my_pairs; }
+            if (ty < tiles_x && tx < tiles_x && (!skip_empty || s_listed[tl]))
+                const_cast<unsigned long long*>(a.masks)[(tile_base + (long)ty * tiles_x + tx) * chunks + c0 + ci] = s_words[tl][ci];
         }
-        if (single || g >= ngroups) break;
+        __syncthreads();
     }
-    __syncthreads();
-    // the queue records of the listed tiles: (tile, first entry, entries, pairs)
-    if (wave == 0 && s_off[lane] >= 0) {
-        const long gt = tile_base + (long)ty_l * tiles_x + tx_l;
-        a.tile_info_raw[queue_begin(0, a.total_tiles) + s_slot[lane]] = make_int4((int)gt, s_off[lane], s_nout[lane], s_pairs[lane]);
+    if (wave != 0) return;
+
+    // tile queues and the tiles' slices of the entry pool.  Usually the 64 tiles belong to one queue; small batches
+    // of small images put several into one wave
+    const long g = tile_base + (long)ty_l * tiles_x + tx_l;
+    const int xq = tile_ok ? queue_of_tile(g, a.total_tiles) : -1;
+    if (!tile_ok) listed_faces = 0;
+    // A super-tile that lies wholly inside the image and lists nothing anywhere becomes ONE entry of the unlisted
+    // queue, -(its first tile) - 1: the forward kernel fills its 64 x 64 pixels with 256-byte row segments instead of
+    // 64 tiles' 32-byte ones (image rows of a multiple of four pixels, for 16-byte stores).
+    if ((is & 3) == 0 && sx * 64 + 64 <= is && sy * 64 + 64 <= is) {
+        const int x0 = __builtin_amdgcn_readlane(xq, 0);
+        if (__ballot(listed_faces == 0 && xq == x0) == ~0ull) {
+            if (lane == 0) {
+                const int base_e = atomicAdd(a.control + (8 + x0) * kCtlStride, 1);
+                a.tile_list[queue_begin(x0 + 1, a.total_tiles) - 1 - base_e] = -(int)g - 1;
+            }
+            GENDR_SPAN_END(1, blockIdx.x);
+            return;
+        }
     }
+    unsigned long long todo = __ballot(tile_ok);
+    while (todo) {
+        const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
+        const unsigned long long mine = __ballot(xq == x);
+        todo &= ~mine;
+        const unsigned long long listed = __ballot(xq == x && listed_faces != 0);
+        const unsigned long long empty = mine & ~listed;
+        int need = 0;
+        const int before = wave_exclusive_scan(xq == x ? listed_faces : 0, need);
+        int base_l = 0, base_e = 0;
+        long base_n = 0;
+        if (lane == 0) {
+            if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
+            if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
+            // Entries handed out so far in region x of the pool.  A 64-bit counter that is only advanced while the request
+            // fits: requests beyond the pool (nothing culled: every tile lists every face, 2.7e9 listings at 2048^2 x 5120
+            // faces x 64) cannot wrap it and land in another region's slice; a request that finds the region exhausted gets
+            // ent_cap8, i.e. no slice (ent_cap8 == 0: this option set has no pool at all, see entry_capacity).
+            if (need) {
+                unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.control + (16 + x) * kCtlStride);
+                base_n = a.ent_cap8;
+                if (a.ent_cap8 > 0 && (long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + need <= a.ent_cap8)
+                    base_n = (long)atomicAdd(ctr, (unsigned long long)need);
+            }
+        }
+        base_l = __builtin_amdgcn_readfirstlane(base_l);
+        base_e = __builtin_amdgcn_readfirstlane(base_e);
+        base_n = ((long)__builtin_amdgcn_readfirstlane((int)(base_n >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base_n);
+        if ((listed >> lane) & 1ull) {
+            const long slot = queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt);
+            const long at = base_n + before;                                    // inside region x of the pool
+            const int off = (at >= 0 && at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL) ? (int)((long)x * a.ent_cap8 + at) : -1;
+            a.tile_list[slot] = (int)g;
+            a.tile_info_raw[slot] = make_int4((int)g, off, 0, 0);               // the coverage kernel fills in the entry count
+        }
+        if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
+    }
+    GENDR_SPAN_END(1, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1125,7 +988,7 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 //
 // Measured on the headline scene: a face touches only ~14 of a tile's 64 pixels, so evaluating "one face per
 // loop iteration, lane = pixel" leaves ~78 % of the lanes idle in the expensive stages.  Instead:
-//   coverage (cheap, once per forward call, tile_cover_kernel): box test, barycentrics, edge reject for every pixel of the
+//   coverage (cheap, once per forward call, cover_kernel): box test, barycentrics, edge reject for every pixel of the
 //            tile against every listed face, lane = (face, pixel row), eight faces per step -> per tile the entries
 //            (face, pixel mask) in ascending face order;
 //   walk     the render kernels append the (pixel, face) pairs of the entries -- in ascending (face, pixel) order --
@@ -1178,6 +1041,142 @@ __device__ __forceinline__ unsigned long long collect_pairs(const TileCtx& t, Re
     barycentrics(q, r, t.xp, t.yp);
     live = live && !beyond_an_edge(q, r);
     return __ballot(live);
+}
+
+// ---------------------------------------------------------------------------------------------
+// coverage: which pixels of the tile does each listed face reach?  (once per forward call, shared by both passes)
+// ---------------------------------------------------------------------------------------------
+// One wavefront per listed tile (the same queue walk as the render kernels).  The tile's mask row is first unpacked
+// into an ascending face list in LDS.  Then eight faces are examined per step: lane = (face slot, pixel row), the lane
+// gathers its face's first record stage with vector loads -- eight records in flight per step instead of one
+// scalar-load round trip per face -- and walks the eight pixels of its row through the exact box / edge tests (same
+// functions, same operands as a per-pixel evaluation).  The eight row bytes of a face are OR-ed together across its
+// lanes; faces that own at least one pixel are appended, in ascending order, to the tile's slice of the entry pool
+// (eight 16-byte stores per step, contiguous).
+constexpr int kListCap = 128;      // faces unpacked per round (>= 64: one mask word must fit)
+
+__device__ __forceinline__ unsigned quad_or(unsigned v)
+{
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    return v;
+}
+
+template <int REC>
+__global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
+{
+    __shared__ int s_flist[kListCap];
+    GENDR_SPAN_BEGIN;
+    TileWalk tw;
+    walk_init(tw, a, 1);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int slot = lane >> 3, prow = lane & 7;
+    for (; tw.next < tw.total; tw.next += tw.stride) {
+        // The queue was appended to as the binning workgroups finished: the super-tiles under the object, with the most
+        // faces to examine here, came last.  The waves take the slots from the back so that those start first.
+        const int slot_c = tw.total - 1 - tw.next;
+        const i4v qi = *(const GENDR_CONST_AS i4v*)(a.tile_info_raw + (tw.qbase + slot_c)); // (tile, first entry) from the binning kernel
+        const int tile = qi.x, off = qi.y;
+        if (off < 0) continue;                      // no room in the pool: the render kernels test this tile themselves
+        TileCtx t;
+        tile_setup(t, a, tile);
+        const float* recs_g = a.records + (long)t.b * a.nf * REC;
+        const unsigned long long* mrow = a.masks + (long)tile * a.chunks;
+        const int row_a = t.y0 + prow;
+        const bool row_ok = row_a < a.is;
+        const float yp_a = pixel_coord(a.is - 1 - row_a, a.is, a.r_is);
+        CoverEnt* out = a.entries + off;
+        int nout = 0;
+        float xs[8];                               // pixel centres of the tile's columns, and the nominal pixel pitch
+#pragma unroll
+        for (int c = 0; c < 8; c++) xs[c] = pixel_coord(t.x0 + c, a.is, a.r_is);
+        const float pitch = (float)(2. * a.r_is);
+        int my_pairs = 0;                          // pixels this lane's (face, row) slots found: summed into the tile's weight
+
+        int word0 = 0, group0 = 0;                 // next 64-word group to load / base word of the loaded one
+        unsigned long long wv = 0ull, nz = 0ull;   // this lane's word of the loaded group / its non-zero words still to unpack
+        bool done = false;
+        while (!done) {
+            // ---- unpack up to kListCap faces
+            int nlist = 0;
+            for (;;) {
+                if (!nz) {
+                    if (word0 >= a.chunks) { done = true; break; }
+                    wv = word0 + lane < a.chunks ? mrow[word0 + lane] : 0ull;
+                    nz = __ballot(wv != 0ull);
+                    group0 = word0;
+                    word0 += 64;
+                    continue;
+                }
+                const int j = __builtin_ctzll(nz);
+                const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(wv >> 32), j) << 32)
+                                           | (unsigned)__builtin_amdgcn_readlane((int)wv, j);
+                const int cnt = __popcll(w);
+                if (nlist + cnt > kListCap) break;                       // the word stays in nz for the next round
+                nz &= nz - 1;
+                if ((w >> lane) & 1ull) s_flist[nlist + __popcll(w & lt)] = (group0 + j) * 64 + lane;
+                nlist += cnt;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- eight faces per step
+            for (int i0 = 0; i0 < nlist; i0 += 8) {
+                const bool has = i0 + slot < nlist;
+                const int fn = s_flist[has ? i0 + slot : i0];
+                float r[kRecStage1];
+                gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
+                unsigned m8 = 0u;
+                // The entries only have to be a superset of the contributing pairs (every pair still meets the reference's
+                // own skip tests in the render kernels), so the barycentrics of a row are stepped from its first pixel
+                // instead of being evaluated eight times: w += a * pitch.  Against the expression the edge thresholds were
+                // derived for (barycentrics(), three roundings) the stepped value is off by at most a dozen roundings of
+                // magnitudes below |a| + |b| + |c| (|x|, |y| <= 1) -- a worst-case count gives 17 roundings = 1.06 * 2^-20 of that
+                // sum: the thresholds are lowered by 2^-19 of it (about 2e-4 pixel) and a pixel is dropped only below them.
+                // NaN and infinite coefficients drop nothing.
+                if (has && row_ok && !(yp_a > r[kRecBox + 3] || yp_a < r[kRecBox + 2])) {
+                    constexpr float kSlack = 1.9073486328125e-06f;                     // 2^-19
+                    float w0 = r[kRecInv + 0] * xs[0] + r[kRecInv + 1] * yp_a + r[kRecInv + 2];
+                    float w1 = r[kRecInv + 3] * xs[0] + r[kRecInv + 4] * yp_a + r[kRecInv + 5];
+                    float w2 = r[kRecInv + 6] * xs[0] + r[kRecInv + 7] * yp_a + r[kRecInv + 8];
+                    const float t0 = r[kRecWCull + 0] - kSlack * (fabsf(r[kRecInv + 0]) + fabsf(r[kRecInv + 1]) + fabsf(r[kRecInv + 2]));
+                    const float t1 = r[kRecWCull + 1] - kSlack * (fabsf(r[kRecInv + 3]) + fabsf(r[kRecInv + 4]) + fabsf(r[kRecInv + 5]));
+                    const float t2 = r[kRecWCull + 2] - kSlack * (fabsf(r[kRecInv + 6]) + fabsf(r[kRecInv + 7]) + fabsf(r[kRecInv + 8]));
+                    const float d0 = r[kRecInv + 0] * pitch, d1 = r[kRecInv + 3] * pitch, d2 = r[kRecInv + 6] * pitch;
+                    const float xlo = r[kRecBox + 0], xhi = r[kRecBox + 1];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const bool live = t.x0 + c < a.is && !(xs[c] > xhi || xs[c] < xlo) && !(w0 < t0 || w1 < t1 || w2 < t2);
+                        m8 |= (live ? 1u : 0u) << c;
+                        w0 += d0; w1 += d1; w2 += d2;
+                    }
+                }
+                my_pairs += __popc(m8);
+                const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
+                const unsigned hi = (unsigned)__shfl_down((int)v, 4);                  // lane 8s reads lane 8s+4 (rows 4-7)
+                const bool owns = prow == 0 && (v | hi) != 0u;
+                const unsigned long long keep = __ballot(owns);
+                if (owns) {
+                    CoverEnt e;
+                    e.fn = fn; e.npix = __popc(v) + __popc(hi); e.lo = v; e.hi = hi;
+                    out[nout + __popcll(keep & lt)] = e;
+                }
+                nout += __popcll(keep);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the tile's (pixel, face) pairs = its weight for order_tiles_kernel: summed across the lanes into lane 63 (an
+        // inclusive scan inside each row of 16 lanes, then the two DPP row broadcasts: six VALU steps, no LDS)
+#define GENDR_DPP_IADD(v, ctrl, rows) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xF, false))
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x111, 0xF);      // row_shr:1
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x112, 0xF);      // row_shr:2
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x114, 0xF);      // row_shr:4
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x118, 0xF);      // row_shr:8
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+        my_pairs = GENDR_DPP_IADD(my_pairs, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
+#undef GENDR_DPP_IADD
+        if (lane == 63) a.tile_info_raw[tw.qbase + slot_c] = make_int4(tile, off, nout, my_pairs);
+    }
+    GENDR_SPAN_END(0, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1370,7 +1369,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const bool wide_ok = !a.p.background_from_buffer && ((reinterpret_cast<unsigned long long>(a.rgba) | (kSil ? 0ull : reinterpret_cast<unsigned long long>(a.aux))) & 15ull) == 0ull;
     for (int r = tw.rank; r < tw.empties; r += tw.stride) {
         const int tile = __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]);
-        // a negative entry is an empty super-tile (see tile_cover_kernel): tiles g0 + 8 rows of 8
+        // a negative entry is an empty super-tile (see bin_faces_kernel): tiles g0 + 8 rows of 8
         const int g0 = tile < 0 ? -tile - 1 : tile;
         if (tile >= 0 || !wide_ok) {
             const int n = tile < 0 ? 64 : 1;
