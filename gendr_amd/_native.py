@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GendrParams(ctypes.Structure):
@@ -39,6 +39,9 @@ class GendrParams(ctypes.Structure):
         ("cull", ctypes.c_int),
         ("clear_ptr", ctypes.c_void_p),
         ("clear_floats", ctypes.c_ulonglong),
+        ("deterministic", ctypes.c_int),
+        ("skip_unlisted_aux", ctypes.c_int),
+        ("pool_entries_max", ctypes.c_ulonglong),
     ]
 
 

@@ -28,23 +28,24 @@ int texture_mode(const gendr_params* p, int T)
 }
 
 typedef void (*render_kernel_t)(const RenderArgs);
+typedef void (*faces_kernel_t)(const RenderArgs, const float*);
 
 // Specialised instantiations: the option sets of BASELINE.json's configs and of the reference's experiment
 // scripts get their own kernel (only their own CDF / t-conorm branch is compiled in); everything else runs
 // the runtime-dispatch kernel of its texture mode, which carries all 18 x 10 branches.
 struct KernelKey { int dist, alpha, rgb, sq, texm; };
-struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; };
+struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; faces_kernel_t det, det_bands; };   // det: deterministic backward (runtime-dispatch rows only)
 
 #define GENDR_SPECIALISE(D, A, RGB, SQ, TEXM) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel<D, A, RGB, SQ, TEXM>, render_backward_kernel<D, A, RGB, SQ, TEXM>, nullptr, nullptr }
 
 // same, with the register budget capped for 6 (forward) / 5 (backward) waves per SIMD
 #define GENDR_SPECIALISE_OCC(D, A, RGB, SQ, TEXM) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_w6<D, A, RGB, SQ, TEXM>, render_backward_kernel_w5<D, A, RGB, SQ, TEXM>, nullptr, nullptr }
 
 // same with explicit register-budget suffixes for the forward / backward kernels (_wl 5/4, _wa 4, _wf 2 waves per SIMD)
 #define GENDR_SPECIALISE_K2(D, A, RGB, SQ, TEXM, KF, KB) \
-    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_##KF<D, A, RGB, SQ, TEXM>, render_backward_kernel_##KB<D, A, RGB, SQ, TEXM> }
+    { {D, A, RGB, SQ, TEXM}, render_forward_kernel_##KF<D, A, RGB, SQ, TEXM>, render_backward_kernel_##KB<D, A, RGB, SQ, TEXM>, nullptr, nullptr }
 #define GENDR_SPECIALISE_K(D, A, RGB, SQ, TEXM, KF, KB) GENDR_SPECIALISE_K2(D, A, RGB, SQ, TEXM, KF, KB)
 
 #ifndef C2B
@@ -70,7 +71,8 @@ const KernelEntry kSpecialised[] = {
 
 // alpha-only runtime-dispatch kernels, by the same four classes as kGeneric
 #define GENDR_SIL_ROW(D, A, K) \
-    { {D, A, kRgbNone, -1, kTexSurfaceN}, render_forward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN>, render_backward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN> }
+    { {D, A, kRgbNone, -1, kTexSurfaceN}, render_forward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN>, render_backward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN>, \
+      render_backward_faces_kernel<D, A, kRgbNone, -1, kTexSurfaceN>, render_backward_bands_kernel<D, A, kRgbNone, -1, kTexSurfaceN> }
 const KernelEntry kGenericSil[2][2] = {
     { GENDR_SIL_ROW(-1, -1, wf), GENDR_SIL_ROW(-1, -2, wf) },
     { GENDR_SIL_ROW(-2, -1, wa), GENDR_SIL_ROW(-2, -2, wl) },
@@ -82,7 +84,8 @@ const KernelEntry kGenericSil[2][2] = {
 // (register budget): _wl light x light, _wa light distributions x all aggregators, _wf whenever the heavy
 // distributions are compiled in (their register need does not fit more than two waves per SIMD without heavy spills).
 #define GENDR_GENERIC_ROW(D, A, TEXM, K) \
-    { {D, A, -1, -1, TEXM}, render_forward_kernel_##K<D, A, -1, -1, TEXM>, render_backward_kernel_##K<D, A, -1, -1, TEXM> }
+    { {D, A, -1, -1, TEXM}, render_forward_kernel_##K<D, A, -1, -1, TEXM>, render_backward_kernel_##K<D, A, -1, -1, TEXM>, \
+      render_backward_faces_kernel<D, A, -1, -1, TEXM>, render_backward_bands_kernel<D, A, -1, -1, TEXM> }
 #define GENDR_GENERIC_CLASS(D, A, K) \
     { GENDR_GENERIC_ROW(D, A, kTexSurface1, K), GENDR_GENERIC_ROW(D, A, kTexVertex, K), GENDR_GENERIC_ROW(D, A, kTexSurfaceN, K) }
 
@@ -92,6 +95,8 @@ const KernelEntry kGeneric[2][2][3] = {
     { GENDR_GENERIC_CLASS(-2, -1, wa), GENDR_GENERIC_CLASS(-2, -2, wl) },
 };
 
+const KernelEntry& pick_generic(const gendr_params* p, int texm, bool silhouette);
+
 const KernelEntry& pick_kernel(const gendr_params* p, int texm, bool silhouette = false)
 {
     const int rgb = silhouette ? kRgbNone : p->aggr_rgb_func;
@@ -100,6 +105,12 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm, bool silhouette 
             e.key.sq == (p->dist_squared ? 1 : 0) && e.key.texm == texm)
             return e;
     }
+    return pick_generic(p, texm, silhouette);
+}
+
+// the runtime-dispatch row of an option set (also the home of the deterministic backward kernels)
+const KernelEntry& pick_generic(const gendr_params* p, int texm, bool silhouette)
+{
     if (silhouette) return kGenericSil[is_light_dist(p->dist_func) ? 1 : 0][is_light_alpha(p->aggr_alpha_func) ? 1 : 0];
     return kGeneric[is_light_dist(p->dist_func) ? 1 : 0][is_light_alpha(p->aggr_alpha_func) ? 1 : 0][texm];
 }
@@ -109,7 +120,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" float gendr_cull_radius(const gendr_params* p);
 
 struct Workspace {
-    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, sorted_off, control_off, total;
+    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, sorted_off, control_off, det_off, total;
     bool ordered;              // the render kernels walk the heavy-first copy of the queue records (order_tiles_kernel)
     int tiles_x, chunks, supers_x, ncontrol;
     long ent_cap8;
@@ -139,6 +150,7 @@ long entry_capacity(long B, long tiles, long nf, const gendr_params* p)
     if (B < 8) want *= 2.;
     if (want > (double)worst) want = (double)worst;
     if (want > (double)0x7fffff00L) want = (double)0x7fffff00L;   // entry offsets are ints
+    if (p->pool_entries_max > 0 && want > (double)p->pool_entries_max) want = (double)p->pool_entries_max;   // caller's limit
     return ((long)want + 7) / 8 * 8;
 }
 
@@ -165,8 +177,39 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16 && w.ent_cap8 > 0;   // (no pool: no pair counts to order by)
     w.control_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
     w.ncontrol = kCtlInts;
-    w.total = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
+    // deterministic backward: [count + list of the deferred faces][their band sums]
+    w.det_off = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
+    const size_t det_bands = (size_t)(p->image_size + kDetBandRows - 1) / kDetBandRows;
+    w.total = w.det_off + (p->deterministic ? align256((size_t)(kDetBigCap + 64) * sizeof(int)) + align256((size_t)kDetBigCap * det_bands * kDetSlots * sizeof(float)) : 0);
     return w;
+}
+
+// gendr_params::deterministic: one wavefront per (image, face), see render_backward_faces_body; the few faces with a large
+// cull box are cut into row bands (second launch) whose sums a third launch adds up in a fixed order.  Uses the scratch region
+// at the end of the workspace (the one part of it that gendr_backward writes).
+int launch_deterministic_backward(RenderArgs& a, const void* workspace, int B, int nf, int T, const gendr_params* p, bool silhouette, void* stream)
+{
+    // XCD x renders the images x, x + 8, ...; kDetThreads / 64 faces per workgroup
+    const long per_xcd = ((long)((B + 7) / 8) * nf + (kDetThreads / 64) - 1) / (kDetThreads / 64);
+    const long blocks = 8L * per_xcd;
+    if (blocks > 0x7fffffffL) return GENDR_E_SHAPE;
+    const Workspace w = workspace_layout(B, nf, T, p);
+    hipStream_t s = (hipStream_t)stream;
+    char* base = static_cast<char*>(const_cast<void*>(workspace));
+    const float* boxes = reinterpret_cast<const float*>(base + w.boxes_off);
+    a.det_count = reinterpret_cast<int*>(base + w.det_off);
+    a.det_list = a.det_count + 64;
+    a.det_partial = reinterpret_cast<float*>(base + w.det_off + align256((size_t)(kDetBigCap + 64) * sizeof(int)));
+    if (hipMemsetAsync(a.det_count, 0, sizeof(int), s) != hipSuccess) return GENDR_E_LAUNCH;
+    const int texm = texture_mode(p, T);
+    const KernelEntry& k = pick_generic(p, texm, silhouette);
+    hipLaunchKernelGGL(k.det, dim3((unsigned)blocks), dim3(kDetThreads), 0, s, a, boxes);
+    if (texm != kTexSurfaceN || silhouette) {
+        hipLaunchKernelGGL(k.det_bands, dim3(8192), dim3(kThreads), 0, s, a, boxes);
+        const int ng = silhouette ? 9 : (texm == kTexSurface1 ? 12 : 18);
+        hipLaunchKernelGGL(det_reduce_kernel, dim3(kDetBigCap), dim3(kThreads), 0, s, a, ng);
+    }
+    return hipGetLastError() == hipSuccess ? GENDR_OK : GENDR_E_LAUNCH;
 }
 
 int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B, int nf, int T, const gendr_params* p)
@@ -465,6 +508,7 @@ int gendr_silhouette_backward(const float* alpha, const void* workspace, const f
     a.grad_faces = grad_faces;
     a.grad_textures = grad_faces;            // never written: the alpha-only kernels have no texture term
     a.p.background_from_buffer = 0;
+    if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, kSilT, p, true, stream);
     const KernelEntry& k = pick_kernel(p, texm, true);
     a.resident_q = resident_per_queue(k.bwd);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
@@ -667,6 +711,7 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.grad_faces = grad_faces;
     a.grad_textures = grad_textures;
     a.p.background_from_buffer = 0;
+    if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, T, p, false, stream);
     const KernelEntry& k = pick_kernel(p, texm);
     a.resident_q = resident_per_queue(k.bwd);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);

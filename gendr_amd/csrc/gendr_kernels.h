@@ -225,6 +225,9 @@ struct RenderArgs {
     long          ent_cap8;     // capacity of one region of the entry pool
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
+    int*   det_count;           // deterministic backward: number of deferred (large-box) faces, their list, their band sums
+    int*   det_list;
+    float* det_partial;
     int resident_q;             // waves of the launched render kernel the chip holds at once, per tile queue (sub-tile split)
     gendr_params p;
     float thr;                  // dist_eps * dist_scale (kernel.cu:725)
@@ -1340,22 +1343,21 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         if constexpr (kSil) { a.rgba[(long)t.b * P + t.pix] = 0.f; return; }
         float* out = a.rgba + (long)t.b * 4 * P + t.pix;
         float* aux = a.aux + (long)t.b * 2 * P + t.pix;
+        const bool with_aux = !a.p.skip_unlisted_aux;      // backward never reads the aggrs_info of an unlisted tile
         out[3 * P] = 0.f;
         if (!rgb_soft) {
             if (!a.p.background_from_buffer) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) out[k * P] = a.p.background[k];
             }
-            aux[0] = 10000000.f;
-            aux[P] = -1.f;
+            if (with_aux) { aux[0] = 10000000.f; aux[P] = -1.f; }
         } else {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float bgk = a.p.background_from_buffer ? out[k * P] : a.p.background[k];
                 out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0;
             }
-            aux[0] = a.softmax_sum0;
-            aux[P] = a.p.aggr_rgb_eps;
+            if (with_aux) { aux[0] = a.softmax_sum0; aux[P] = a.p.aggr_rgb_eps; }
         }
     };
     // 64 x 64 pixels of one plane from `first` (16-byte aligned): lane = (row & 3, 4 pixels), sixteen 1-KiB stores
@@ -1387,8 +1389,10 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         for (int k = 0; k < 3; k++)
             fill_plane(out + k * P, rgb_soft ? (a.p.background[k] * a.softmax_sum0) / a.softmax_sum0 : a.p.background[k]);
         fill_plane(out + 3 * P, 0.f);
-        fill_plane(aux, rgb_soft ? a.softmax_sum0 : 10000000.f);
-        fill_plane(aux + P, rgb_soft ? a.p.aggr_rgb_eps : -1.f);
+        if (!a.p.skip_unlisted_aux) {
+            fill_plane(aux, rgb_soft ? a.softmax_sum0 : 10000000.f);
+            fill_plane(aux + P, rgb_soft ? a.p.aggr_rgb_eps : -1.f);
+        }
     }
 #endif
 
@@ -1585,13 +1589,221 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward
+// backward of one (pixel, face) pair: kernel.cu:965-1052.  Recomputes the pair exactly as the forward kernel does (whatever
+// decides which pairs contribute) and forms the partials of the 9 vertex components (gv) and of the face's texture
+// (gt: 3 texel components for surface T = 1, 9 vertex-colour components; surface T > 1: the one texel `tex_own` of the
+// face's block that receives tex_val[3], or -1).  Returns false when the pair contributes nothing (gv / gt are then
+// undefined).  Shared by the tile kernel (lane = pair of a batch) and the per-face deterministic kernel (lane = pixel).
 // ---------------------------------------------------------------------------------------------
 template <int TEXM> struct GradSlots { static constexpr int n = TEXM == kTexSurface1 ? 12 : (TEXM == kTexVertex ? 18 : 9); };
+template <int TEXM> struct GradTex { static constexpr int n = GradSlots<TEXM>::n > 9 ? GradSlots<TEXM>::n - 9 : 1; };
 
 struct PixIn {             // 48 bytes: per-pixel inputs of the backward pass, kernel.cu:916-917, :973, :980, :1013, :1021
     float g[4], out[4], ssum, smax, xp, yp;
 };
+
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, bool PRELOADED = false>
+__device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistParams& dp, const float* rg, const PixIn& px, int fn, long face_lin,
+                                              float (&gv)[9], float (&gt)[GradTex<TEXM>::n], int& tex_own, float (&tex_val)[3])
+{
+    constexpr int REC = record_floats(TEXM);
+    constexpr int NT = GradTex<TEXM>::n;
+    constexpr bool kSil = RGB == kRgbNone;
+    const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
+    const int dist = DIST >= 0 ? DIST : a.p.dist_func;
+    const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
+    const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
+    // PRELOADED: rg is the caller's register copy of the whole record (one face per wavefront: loaded once, not per pair)
+    float r[REC];
+    if constexpr (PRELOADED) {
+#pragma unroll
+        for (int k = 0; k < REC; k++) r[k] = rg[k];
+    } else {
+        gather_record<kGatherW0, kGatherW1>(r, rg);
+        gather_record<kGatherA0, kGatherA1>(r, rg);
+    }
+    const float pxp = px.xp, pyp = px.yp;
+    Pair q;
+    barycentrics(q, r, pxp, pyp);
+    // Two stages one after the other, not nested: `live` is narrowed by the first and guards the second, and the
+    // partials are defined in the second only (as values that survive a nest of early exits they were
+    // re-initialised at every level of it: 58 moves per batch; the empty asm below keeps the compiler from turning
+    // the final select back into such a default).
+    float C_xy = 0.f, zp = 0.f;
+    float wc[3];
+    bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp);
+    if (live) {
+        // alpha only, and this face's depth cannot fail the near / far test (see face_setup_kernel): no depth stage
+        const bool need_depth = !(kSil && (__float_as_int(r[kRecBits]) & kBitDepthSafe));
+        if constexpr (!PRELOADED) { if (need_depth) gather_record<kGatherB0, REC / 4>(r, rg); }
+        // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
+        float C_alpha = px.g[3];
+        if (alpha_func != kAlphaHard) {
+            if constexpr ((ALPHA == kProbabilistic || ALPHA == kEinstein) && !GENDR_EXACT_GRADIENT)
+                                            C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad_fp32(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+            else if constexpr (ALPHA > 0)   C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+            else if constexpr (ALPHA == -2) C_alpha *= tconorm_grad_light_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+            else                            C_alpha *= tconorm_grad_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
+        }
+        C_xy += C_alpha;
+
+        if (need_depth) {
+            zp = clip_and_depth(q, r, wc);
+            live = !(zp < a.p.near_ || zp > a.p.far_);                  // :994 drops the whole pair
+        }
+    }
+    {
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) gv[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NT; k++) gt[k] = 0.f;
+            const bool front = (__float_as_int(r[kRecBits]) & kBitFront) != 0;
+            if constexpr (kSil) {
+                // no colour term: C_xy stays the alpha partial
+            } else if (!rgb_soft) {                                     // :997-1004
+                if ((float)fn == px.smax) {
+                    if constexpr (TEXM == kTexVertex) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+#pragma unroll
+                            for (int j = 0; j < 3; j++) gt[3 * j + k] = wc[j] * px.g[k];
+                    } else {
+                        float cc[3]; int own;
+                        sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
+                        if (own >= 0) {
+                            if constexpr (TEXM == kTexSurface1) {
+#pragma unroll
+                                for (int k = 0; k < 3; k++) gt[k] = px.g[k];
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 3; k++)
+                                    unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, px.g[k]);
+                            }
+                        }
+                    }
+                }
+            } else if (front || a.p.double_side) {                      // :1006-1030
+                const float zn = div_by(a.p.far_ - zp, a.r_zrange);
+                const float zs = grad_div(q.frag * expf(div_by(zn - px.smax, a.r_gamma)), px.ssum);   // :1010
+                float cc[3]; int own;
+                sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
+                float C_rgb = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if constexpr (TEXM == kTexVertex) {
+#pragma unroll
+                        for (int j = 0; j < 3; j++) gt[3 * j + k] = zs * (wc[j] * px.g[k]);
+                    } else if constexpr (TEXM == kTexSurface1) {
+                        if (own >= 0) gt[k] = zs * px.g[k];
+                    } else {
+                        if (own >= 0) { tex_own = own; tex_val[k] = zs * px.g[k]; }
+                    }
+                    C_rgb += px.g[k] * (cc[k] - px.out[k]);             // :1021
+                }
+                C_rgb *= zs;                                            // :1023
+                C_xy += grad_div(C_rgb, q.frag);                        // :1024
+#if GENDR_EXACT_GRADIENT
+                const float C_z = div_by(div_by(C_rgb, a.r_gamma), a.r_nzrange) * zp * zp;   // :1026
+                gv[2] = div_by(div_by(C_z * wc[0], rec_double(r, kRecRZ + 0)), rec_double(r, kRecRZ + 0));
+                gv[5] = div_by(div_by(C_z * wc[1], rec_double(r, kRecRZ + 2)), rec_double(r, kRecRZ + 2));
+                gv[8] = div_by(div_by(C_z * wc[2], rec_double(r, kRecRZ + 4)), rec_double(r, kRecRZ + 4));
+#else
+                // C_rgb / gamma / (near - far) * zp^2 * w_k / z_k^2 with the float reciprocals (:1026-1029)
+                const float C_z = C_rgb * ((float)a.r_gamma * (float)a.r_nzrange) * zp * zp;
+                const float rz0 = (float)rec_double(r, kRecRZ + 0), rz1 = (float)rec_double(r, kRecRZ + 2), rz2 = (float)rec_double(r, kRecRZ + 4);
+                gv[2] = C_z * wc[0] * (rz0 * rz0);
+                gv[5] = C_z * wc[1] * (rz1 * rz1);
+                gv[8] = C_z * wc[2] * (rz2 * rz2);
+#endif
+            }
+
+            // distance gradient, kernel.cu:1034-1052.  Heaviside: D' = 0 times uninitialised
+            // values in the reference -> defined as exactly 0 here (DESIGN.md quirk i).
+            if (dist != kHeaviside) {
+                if constexpr (DIST == kLogistic) C_xy *= div_by(q.frag * (1 - q.frag), dp.rscale);   // :378-380: y is the CDF just computed
+                else if constexpr (DIST >= 0)  C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
+                else if constexpr (DIST == -2) C_xy *= pdf_light_rt(dist, q.sign, q.dis, dp);
+                else                           C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
+                const float tw[3] = {q.t0 + q.w0, q.t1 + q.w1, q.t2 + q.w2};
+                if (squared) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        gv[3 * k + 0] = 2 * q.sign * C_xy * tw[k] * q.dx;
+                        gv[3 * k + 1] = 2 * q.sign * C_xy * tw[k] * q.dy;
+                    }
+                } else {
+                    // (double)num / max(sqrt(dx^2+dy^2), 1e-6), rounded to float (:1049).  When the divisor is
+                    // the float square root, one double reciprocal serves all six quotients exactly (div_by);
+                    // below 1e-6 the divisor is the double literal and the true divisions are kept.
+                    const float len = q.dis;   // == sqrtf(dx*dx + dy*dy): the very value soft_fragment() computed (:771)
+#if GENDR_EXACT_GRADIENT
+                    if ((double)len >= 1e-6) {
+                        const double rlen = rcp_for_div_by((double)len);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            gv[3 * k + 0] = div_by(q.sign * C_xy * tw[k] * q.dx, rlen);
+                            gv[3 * k + 1] = div_by(q.sign * C_xy * tw[k] * q.dy, rlen);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            gv[3 * k + 0] = (float)((double)(q.sign * C_xy * tw[k] * q.dx) / 1e-6);
+                            gv[3 * k + 1] = (float)((double)(q.sign * C_xy * tw[k] * q.dy) / 1e-6);
+                        }
+                    }
+#else
+                    const float rlen = ((double)len >= 1e-6) ? grad_rcp(len) : 1e6f;
+                    const float sx = q.sign * C_xy * (q.dx * rlen), sy = q.sign * C_xy * (q.dy * rlen);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        gv[3 * k + 0] = sx * tw[k];
+                        gv[3 * k + 1] = sy * tw[k];
+                    }
+#endif
+                }
+            }
+        }
+    }
+    return live;
+}
+
+// the per-pixel inputs of the backward pass (zeros for a lane without a pixel)
+template <int RGB>
+__device__ __forceinline__ PixIn load_pixel_inputs(const RenderArgs& a, int b, long pix, bool valid, float xp, float yp)
+{
+    constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` / `grad_rgba` are single planes, see RenderArgs
+    const long P = (long)a.is * a.is;
+    PixIn pi;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { pi.g[k] = 0.f; pi.out[k] = 0.f; }
+    pi.ssum = 1.f; pi.smax = 0.f; pi.xp = xp; pi.yp = yp;
+    if (kSil) {
+        if (valid) {
+            pi.out[3] = a.rgba[(long)b * P + pix];
+            if (a.grad_iou) {
+                // d loss / d alpha of the fused IoU sums: g1 * t + g2 * (1 - t)
+                const float tv = a.target[(long)b * P + pix];
+                pi.g[3] = a.grad_iou[2 * b] * tv + a.grad_iou[2 * b + 1] * (1.f - tv);
+            } else {
+                pi.g[3] = a.grad_rgba[(long)b * P + pix];
+            }
+        }
+    } else if (valid) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            pi.g[k] = a.grad_rgba[((long)b * 4 + k) * P + pix];
+            pi.out[k] = a.rgba[((long)b * 4 + k) * P + pix];
+        }
+        pi.ssum = a.aux[((long)b * 2 + 0) * P + pix];
+        pi.smax = a.aux[((long)b * 2 + 1) * P + pix];
+    }
+    return pi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
@@ -1637,33 +1849,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     TileCtx t;
     tile_setup(t, a, ti.x);
     t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels whose pairs this wave differentiates
-    {
-        PixIn pi;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { pi.g[k] = 0.f; pi.out[k] = 0.f; }
-        pi.ssum = 1.f; pi.smax = 0.f; pi.xp = t.xp; pi.yp = t.yp;
-        if (kSil) {
-            if (t.valid) {
-                pi.out[3] = a.rgba[(long)t.b * P + t.pix];
-                if (a.grad_iou) {
-                    // d loss / d alpha of the fused IoU sums: g1 * t + g2 * (1 - t)
-                    const float tv = a.target[(long)t.b * P + t.pix];
-                    pi.g[3] = a.grad_iou[2 * t.b] * tv + a.grad_iou[2 * t.b + 1] * (1.f - tv);
-                } else {
-                    pi.g[3] = a.grad_rgba[(long)t.b * P + t.pix];
-                }
-            }
-        } else if (t.valid) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                pi.g[k] = a.grad_rgba[((long)t.b * 4 + k) * P + t.pix];
-                pi.out[k] = a.rgba[((long)t.b * 4 + k) * P + t.pix];
-            }
-            pi.ssum = a.aux[((long)t.b * 2 + 0) * P + t.pix];
-            pi.smax = a.aux[((long)t.b * 2 + 1) * P + t.pix];
-        }
-        s_pix[wave][lane] = pi;
-    }
+    s_pix[wave][lane] = load_pixel_inputs<RGB>(a, t.b, t.pix, t.valid, t.xp, t.yp);
     GENDR_T(1);                                   // 1: tile record + the pixel's inputs parked in LDS
 #if GENDR_TRACE
     if (!tr[2]) GENDR_STAMP(2);
@@ -1698,164 +1884,15 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             const PixIn px = s_pix[wave][code & 63];
             const int fn = fn_l;
             const long face_lin = (long)t.b * a.nf + fn;
-            float r[REC];
-            const float* rg = recs_g + (long)fn * REC;
-            gather_record<kGatherW0, kGatherW1>(r, rg);
-            gather_record<kGatherA0, kGatherA1>(r, rg);
-            GENDR_T(3);                           // 3: pair code, pixel inputs, first record gather landed
-            const float pxp = px.xp, pyp = px.yp;
-            Pair q;
-            barycentrics(q, r, pxp, pyp);
-#ifdef GENDR_PAD_VALU
-            {   // diagnostic: GENDR_PAD_VALU extra independent VALU instructions per batch (how VALU-bound is the kernel?)
-                int p0 = lane, p1 = lane, p2 = lane, p3 = lane;
-#pragma unroll
-                for (int i = 0; i < GENDR_PAD_VALU / 4; i++)
-                    asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
-                if (p0 + p1 + p2 + p3 == 0x7fffffff) q.w0 = 0.f;
-            }
-#endif
-
-            // Two stages one after the other, not nested: `live` is narrowed by the first and guards the second, and the
-            // partials are defined in the second only (as values that survive a nest of early exits they were
-            // re-initialised at every level of it: 58 moves per batch; the empty asm below keeps the compiler from turning
-            // the final select back into such a default).
             float gv[9];                       // d loss / d (x,y,z) of the 3 vertices, kernel.cu:967
             float gt[NT];                      // texture partials
-            float C_xy = 0.f, zp = 0.f;
-            float wc[3];
-            bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp);
-            if (live) {
-                // alpha only, and this face's depth cannot fail the near / far test (see face_setup_kernel): no depth stage
-                const bool need_depth = !(kSil && (__float_as_int(r[kRecBits]) & kBitDepthSafe));
-                if (need_depth) gather_record<kGatherB0, REC / 4>(r, rg);
-                // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
-                float C_alpha = px.g[3];
-                if (alpha_func != kAlphaHard) {
-                    if constexpr ((ALPHA == kProbabilistic || ALPHA == kEinstein) && !GENDR_EXACT_GRADIENT)
-                                                    C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad_fp32(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                    else if constexpr (ALPHA > 0)   C_alpha *= TConorm<(ALPHA > 0 ? ALPHA : 1)>::grad(px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                    else if constexpr (ALPHA == -2) C_alpha *= tconorm_grad_light_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                    else                            C_alpha *= tconorm_grad_rt(alpha_func, px.out[3], q.frag, a.p.aggr_alpha_t_conorm_p);
-                }
-                C_xy += C_alpha;
-
-                if (need_depth) {
-                    zp = clip_and_depth(q, r, wc);
-                    live = !(zp < a.p.near_ || zp > a.p.far_);                  // :994 drops the whole pair
-                }
-            }
-            {
-                if (live) {
+            int tex_own = -1;
+            float tex_val[3] = {0.f, 0.f, 0.f};
+            const bool live = backward_pair<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, recs_g + (long)fn * REC, px, fn, face_lin, gv, gt, tex_own, tex_val);
+            if constexpr (TEXM == kTexSurfaceN) {
+                if (live && tex_own >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 9; k++) gv[k] = 0.f;
-#pragma unroll
-                    for (int k = 0; k < NT; k++) gt[k] = 0.f;
-                    const bool front = (__float_as_int(r[kRecBits]) & kBitFront) != 0;
-                    if constexpr (kSil) {
-                        // no colour term: C_xy stays the alpha partial
-                    } else if (!rgb_soft) {                                     // :997-1004
-                        if ((float)fn == px.smax) {
-                            if constexpr (TEXM == kTexVertex) {
-#pragma unroll
-                                for (int k = 0; k < 3; k++)
-#pragma unroll
-                                    for (int j = 0; j < 3; j++) gt[3 * j + k] = wc[j] * px.g[k];
-                            } else {
-                                float cc[3]; int own;
-                                sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
-                                if (own >= 0) {
-                                    if constexpr (TEXM == kTexSurface1) {
-#pragma unroll
-                                        for (int k = 0; k < 3; k++) gt[k] = px.g[k];
-                                    } else {
-#pragma unroll
-                                        for (int k = 0; k < 3; k++)
-                                            unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, px.g[k]);
-                                    }
-                                }
-                            }
-                        }
-                    } else if (front || a.p.double_side) {                      // :1006-1030
-                        const float zn = div_by(a.p.far_ - zp, a.r_zrange);
-                        const float zs = grad_div(q.frag * expf(div_by(zn - px.smax, a.r_gamma)), px.ssum);   // :1010
-                        float cc[3]; int own;
-                        sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
-                        float C_rgb = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            if constexpr (TEXM == kTexVertex) {
-#pragma unroll
-                                for (int j = 0; j < 3; j++) gt[3 * j + k] = zs * (wc[j] * px.g[k]);
-                            } else if constexpr (TEXM == kTexSurface1) {
-                                if (own >= 0) gt[k] = zs * px.g[k];
-                            } else {
-                                if (own >= 0) unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + own) * 3 + k, zs * px.g[k]);
-                            }
-                            C_rgb += px.g[k] * (cc[k] - px.out[k]);             // :1021
-                        }
-                        C_rgb *= zs;                                            // :1023
-                        C_xy += grad_div(C_rgb, q.frag);                        // :1024
-#if GENDR_EXACT_GRADIENT
-                        const float C_z = div_by(div_by(C_rgb, a.r_gamma), a.r_nzrange) * zp * zp;   // :1026
-                        gv[2] = div_by(div_by(C_z * wc[0], rec_double(r, kRecRZ + 0)), rec_double(r, kRecRZ + 0));
-                        gv[5] = div_by(div_by(C_z * wc[1], rec_double(r, kRecRZ + 2)), rec_double(r, kRecRZ + 2));
-                        gv[8] = div_by(div_by(C_z * wc[2], rec_double(r, kRecRZ + 4)), rec_double(r, kRecRZ + 4));
-#else
-                        // C_rgb / gamma / (near - far) * zp^2 * w_k / z_k^2 with the float reciprocals (:1026-1029)
-                        const float C_z = C_rgb * ((float)a.r_gamma * (float)a.r_nzrange) * zp * zp;
-                        const float rz0 = (float)rec_double(r, kRecRZ + 0), rz1 = (float)rec_double(r, kRecRZ + 2), rz2 = (float)rec_double(r, kRecRZ + 4);
-                        gv[2] = C_z * wc[0] * (rz0 * rz0);
-                        gv[5] = C_z * wc[1] * (rz1 * rz1);
-                        gv[8] = C_z * wc[2] * (rz2 * rz2);
-#endif
-                    }
-
-                    // distance gradient, kernel.cu:1034-1052.  Heaviside: D' = 0 times uninitialised
-                    // values in the reference -> defined as exactly 0 here (DESIGN.md quirk i).
-                    if (dist != kHeaviside) {
-                        if constexpr (DIST == kLogistic) C_xy *= div_by(q.frag * (1 - q.frag), dp.rscale);   // :378-380: y is the CDF just computed
-                        else if constexpr (DIST >= 0)  C_xy *= Dist<(DIST >= 0 ? DIST : 0)>::pdf(q.sign, q.dis, dp);
-                        else if constexpr (DIST == -2) C_xy *= pdf_light_rt(dist, q.sign, q.dis, dp);
-                        else                           C_xy *= pdf_rt(dist, q.sign, q.dis, dp);
-                        const float tw[3] = {q.t0 + q.w0, q.t1 + q.w1, q.t2 + q.w2};
-                        if (squared) {
-#pragma unroll
-                            for (int k = 0; k < 3; k++) {
-                                gv[3 * k + 0] = 2 * q.sign * C_xy * tw[k] * q.dx;
-                                gv[3 * k + 1] = 2 * q.sign * C_xy * tw[k] * q.dy;
-                            }
-                        } else {
-                            // (double)num / max(sqrt(dx^2+dy^2), 1e-6), rounded to float (:1049).  When the divisor is
-                            // the float square root, one double reciprocal serves all six quotients exactly (div_by);
-                            // below 1e-6 the divisor is the double literal and the true divisions are kept.
-                            const float len = q.dis;   // == sqrtf(dx*dx + dy*dy): the very value soft_fragment() computed (:771)
-#if GENDR_EXACT_GRADIENT
-                            if ((double)len >= 1e-6) {
-                                const double rlen = rcp_for_div_by((double)len);
-#pragma unroll
-                                for (int k = 0; k < 3; k++) {
-                                    gv[3 * k + 0] = div_by(q.sign * C_xy * tw[k] * q.dx, rlen);
-                                    gv[3 * k + 1] = div_by(q.sign * C_xy * tw[k] * q.dy, rlen);
-                                }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 3; k++) {
-                                    gv[3 * k + 0] = (float)((double)(q.sign * C_xy * tw[k] * q.dx) / 1e-6);
-                                    gv[3 * k + 1] = (float)((double)(q.sign * C_xy * tw[k] * q.dy) / 1e-6);
-                                }
-                            }
-#else
-                            const float rlen = ((double)len >= 1e-6) ? grad_rcp(len) : 1e6f;
-                            const float sx = q.sign * C_xy * (q.dx * rlen), sy = q.sign * C_xy * (q.dy * rlen);
-#pragma unroll
-                            for (int k = 0; k < 3; k++) {
-                                gv[3 * k + 0] = sx * tw[k];
-                                gv[3 * k + 1] = sy * tw[k];
-                            }
-#endif
-                        }
-                    }
+                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + tex_own) * 3 + k, tex_val[k]);
                 }
             }
             GENDR_T(4);                           // 4: the pair math (incl. the second gather)
@@ -1948,6 +1985,248 @@ template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GENDR_HALPHA_WAVES))) void render_backward_kernel_wa(const RenderArgs a)
 {
     render_backward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic backward (gendr_params::deterministic): one wavefront per (image, face), no atomics
+// ---------------------------------------------------------------------------------------------
+// The tile kernel adds a face's partial sums with hardware fp32 atomics: one per (tile batch, face, component), in the order
+// the tiles happen to be dispatched -- like the reference's atomicAdd per (pixel, face) (kernel.cu:1054-1063), the result
+// differs in the last bits from run to run (experiments/train_reconstruction.py:582-586 warns about it).  This kernel
+// gathers instead: the wavefront of a face walks the pixels of the face's cull box in raster order, 64 at a time
+// (lane = pixel), applies the exact per-pixel tests and the same backward_pair() as the tile kernel, keeps one running sum
+// per lane and component (a pixel of the box always lands on the same lane, in the same order), and combines the 64 lane sums
+// in a fixed butterfly at the end.  Every gradient element has exactly one writer and one summation order: two calls on the
+// same inputs return bit-identical gradients, whatever the batch, the dispatch order or the build's tile size.
+// It needs nothing from the tile queues (only the face records and cull boxes), and costs what a gather costs: the lanes
+// of a 64-pixel step that fall outside the triangle idle (measured at C2: see DESIGN.md).
+constexpr int kDetBigSteps = 64;      // a face whose cull box takes more 64-pixel steps than this goes to the band kernel
+constexpr int kDetBandRows = 8;       // image rows per work item of the band kernel
+constexpr int kDetBigCap = 2048;      // deferred faces the scratch region of the workspace holds
+constexpr int kDetSlots = 18;         // floats per partial row (the largest GradSlots)
+#ifndef GENDR_DET_THREADS
+#define GENDR_DET_THREADS 256
+#endif
+constexpr int kDetThreads = GENDR_DET_THREADS;     // wavefronts (= faces) per workgroup x 64
+
+struct DetBox { int x0, W, yi0, yi1; bool empty; };
+
+// the pixels whose centres can lie inside the face's cull box: index of the first / last pixel centre inside [lo, hi], in
+// double with a thousandth of a pixel of slack (a centre is correctly rounded from an integer: off by < 1e-7 of the image);
+// pixel centre of index i: (2 i + 1 - is) / is
+__device__ __forceinline__ DetBox det_box(const RenderArgs& a, const float* __restrict__ boxes, long face_lin)
+{
+    const float4 box = reinterpret_cast<const float4*>(boxes)[face_lin * (kBinRec / 4)];
+    const double is_d = (double)a.is;
+    auto first_index = [&](float v) { const double f = ceil(((double)v * is_d + is_d - 1.) * 0.5 - 1e-3); return f != f ? 0 : (int)fmin(fmax(f, 0.), is_d - 1.); };
+    auto last_index = [&](float v) { const double f = floor(((double)v * is_d + is_d - 1.) * 0.5 + 1e-3); return f != f ? a.is - 1 : (int)fmin(fmax(f, 0.), is_d - 1.); };
+    DetBox d;
+    d.empty = box.x > box.y || box.z > box.w;                            // (NaN boxes fall through: whole image)
+    d.x0 = first_index(box.x);
+    d.W = last_index(box.y) - d.x0 + 1;
+    d.yi0 = first_index(box.z);
+    d.yi1 = last_index(box.w);
+    if (d.W <= 0 || d.yi1 < d.yi0) d.empty = true;
+    return d;
+}
+
+// Rows [ya, yb] (indices from the bottom of the image, kernel.cu:716) of the face's box: per lane and component the sum of
+// the partials of the lane's pixels, in raster order.  lane -> pixel: rows of up to 64 pixels; a narrower box puts 64 / W
+// rows into one step (one division per wavefront); a pixel always lands on the same lane and step for given (W, ya).
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__device__ __forceinline__ void det_rows(const RenderArgs& a, const DistParams& dp, const float (&rec)[record_floats(TEXM)], int b, int fn, long face_lin,
+                                         int x0, int W, int ya, int yb, float (&acc)[GradSlots<TEXM>::n])
+{
+    constexpr int NG = GradSlots<TEXM>::n, NT = GradTex<TEXM>::n;
+    const int lane = threadIdx.x & 63;
+    const double is_d = (double)a.is;
+    const int wp = min(W, 64), rows_per_step = 64 / wp;
+    const int ry_l = lane / wp, rx_l = lane - ry_l * wp;
+    const bool lane_used = ry_l < rows_per_step;
+    for (int yr = ya; yr <= yb; yr += rows_per_step) {
+    // A wide box (one row per step) of a thin face is mostly empty: the three edge tests are linear in x, so the stretch of
+    // the row that can pass them is an interval -- computed in double with a pixel of slack on either side (every pixel
+    // still takes the exact tests below).
+    int rx_first = 0, rx_last = W - 1;
+    if (wp == 64) {
+        const double ypd = (double)pixel_coord(yr, a.is, a.r_is);
+        double xa = -1e30, xb = 1e30;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double ea = rec[kRecInv + 3 * k], eb = rec[kRecInv + 3 * k + 1], ec = rec[kRecInv + 3 * k + 2], et = rec[kRecWCull + k];
+            if (et > -1e30 && ea == ea && fabs(ea) < 1e30 && ea != 0.) {
+                const double rhs = (et - 1e-5 * (fabs(ea) + fabs(eb) + fabs(ec) + fabs(et))) - (eb * ypd + ec);
+                const double x = rhs / ea;
+                if (x == x) { if (ea > 0.) xa = fmax(xa, x); else xb = fmin(xb, x); }
+            }
+        }
+        const double ia = floor((xa * is_d + is_d - 1.) * 0.5) - 1. - x0, ib = ceil((xb * is_d + is_d - 1.) * 0.5) + 1. - x0;
+        rx_first = __builtin_amdgcn_readfirstlane((int)fmin(fmax(ia, 0.), (double)W));
+        rx_last = __builtin_amdgcn_readfirstlane((int)fmax(fmin(ib, (double)(W - 1)), -1.));
+    }
+    for (int rx0 = rx_first; rx0 <= rx_last; rx0 += wp) {
+        const int rx = rx0 + rx_l, yi = yr + ry_l;
+        const int xi = x0 + rx;
+        const float xp = pixel_coord(xi, a.is, a.r_is), yp = pixel_coord(yi, a.is, a.r_is);
+        bool live = lane_used && rx < W && yi <= yb && inside_box(rec, xp, yp);
+        Pair q0;
+        barycentrics(q0, rec, xp, yp);
+        live = live && !beyond_an_edge(q0, rec);
+        if (!__any(live)) continue;
+        const long pix = (long)(a.is - 1 - yi) * a.is + xi;              // row 0 = top: yi = is - 1 - row (kernel.cu:716)
+        const PixIn px = load_pixel_inputs<RGB>(a, b, pix, live, xp, yp);
+        float gv[9], gt[NT];
+        int tex_own = -1;
+        float tex_val[3] = {0.f, 0.f, 0.f};
+        bool ok = false;
+        if (live) ok = backward_pair<DIST, ALPHA, RGB, SQ, TEXM, true>(a, dp, rec, px, fn, face_lin, gv, gt, tex_own, tex_val);
+#pragma unroll
+        for (int k = 0; k < 9; k++) asm("" : "+v"(gv[k]));
+#pragma unroll
+        for (int k = 0; k < NG - 9; k++) asm("" : "+v"(gt[k]));
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc[k] += ok ? gv[k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NG - 9; k++) acc[9 + k] += ok ? gt[k] : 0.f;
+        if constexpr (TEXM == kTexSurfaceN) {
+            // surface texels, T > 1: a pair feeds one texel of the face's block; texel by texel, a fixed butterfly over the
+            // lanes and one writer (the rows of a face are walked in ascending order by exactly one wavefront at a time:
+            // the band kernel leaves these faces to the per-face kernel)
+            if (!ok) tex_own = -1;
+            for (int j = 0; j < a.T; j++) {
+                if (!__any(tex_own == j)) continue;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float v = tex_own == j ? tex_val[k] : 0.f;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                    if (lane == 0) a.grad_textures[(face_lin * a.T + j) * 3 + k] += v;
+                }
+            }
+        }
+    }
+    }
+}
+
+// the 64 lane sums of every component, combined in a fixed butterfly; lane k returns component k
+template <int NG>
+__device__ __forceinline__ float det_combine(const float (&acc)[NG])
+{
+    const int lane = threadIdx.x & 63;
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        float v = acc[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == k) mine = v;
+    }
+    return mine;
+}
+
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__device__ __forceinline__ void render_backward_faces_body(const RenderArgs& a, const float* __restrict__ boxes)
+{
+    constexpr int REC = record_floats(TEXM);
+    constexpr int NG = GradSlots<TEXM>::n;
+    const int lane = threadIdx.x & 63;
+    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    // Workgroups are dispatched round-robin over the 8 XCDs: XCD x takes the images x, x + 8, ... one after the other, so
+    // that the planes of the image its waves are gathering from stay in that XCD's L2.
+    const int xcd = blockIdx.x & 7;
+    const long j = (long)(blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);     // kDetThreads / 64 faces per workgroup
+    const int b = xcd + 8 * (int)(j / a.nf), fn = (int)(j % a.nf);
+    if (b >= a.B) return;
+    const long face_lin = (long)b * a.nf + fn;
+    const DetBox d = det_box(a, boxes, face_lin);
+    if (d.empty) return;
+    // A box that takes many steps -- a sliver whose cull box degenerated to a large part of the image (23 of the 81920 faces
+    // of the headline batch, but one wavefront scanning 256^2 pixels alone takes as long as all the others together) -- is
+    // left to the band kernel, which cuts it into bands of kDetBandRows rows.
+    if ((TEXM != kTexSurfaceN || RGB == kRgbNone) && a.det_list) {
+        const int wp = min(d.W, 64), rows_per_step = 64 / wp;
+        const long steps = (long)((d.yi1 - d.yi0) / rows_per_step + 1) * ((d.W + wp - 1) / wp);
+        if (steps > kDetBigSteps) {
+            int at = 0;
+            if (lane == 0) at = atomicAdd(a.det_count, 1);
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (at < kDetBigCap) {
+                if (lane == 0) a.det_list[at] = (int)face_lin;
+                return;
+            }
+        }
+    }
+    float rec[REC];
+    load_record<0, REC>(rec, (RecPtr)a.records + face_lin * REC);         // the whole record, wave-uniform: scalar loads
+    float acc[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) acc[k] = 0.f;
+    det_rows<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, rec, b, fn, face_lin, d.x0, d.W, d.yi0, d.yi1, acc);
+    // lane k adds component k to the gradient -- one read-modify-write round trip for all of them
+    const float mine = det_combine<NG>(acc);
+    if (lane < NG) {
+        float* dst = lane < 9 ? a.grad_faces + face_lin * 9 + lane : a.grad_textures + face_lin * (NG - 9) + (lane - 9);
+        *dst += mine;
+    }
+}
+
+// deferred faces: one work item = (face, band of kDetBandRows image rows); its component sums go to a row of the scratch
+// region, every row has exactly one writer
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__device__ __forceinline__ void render_backward_bands_body(const RenderArgs& a, const float* __restrict__ boxes)
+{
+    constexpr int REC = record_floats(TEXM);
+    constexpr int NG = GradSlots<TEXM>::n;
+    const int lane = threadIdx.x & 63;
+    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    const int n = min(__builtin_amdgcn_readfirstlane(*a.det_count), kDetBigCap);
+    const int nbands = (a.is + kDetBandRows - 1) / kDetBandRows;
+    const long items = (long)n * nbands;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int bi = (int)(item / nbands), band = (int)(item - (long)bi * nbands);
+        const long face_lin = a.det_list[bi];
+        const int b = (int)(face_lin / a.nf), fn = (int)(face_lin - (long)b * a.nf);
+        const DetBox d = det_box(a, boxes, face_lin);
+        float acc[NG];
+#pragma unroll
+        for (int k = 0; k < NG; k++) acc[k] = 0.f;
+        const int ya = max(d.yi0, band * kDetBandRows), yb = min(d.yi1, band * kDetBandRows + kDetBandRows - 1);
+        if (!d.empty && ya <= yb) {
+            float rec[REC];
+            load_record<0, REC>(rec, (RecPtr)a.records + face_lin * REC);
+            det_rows<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, rec, b, fn, face_lin, d.x0, d.W, ya, yb, acc);
+        }
+        const float mine = det_combine<NG>(acc);
+        if (lane < NG) a.det_partial[(item) * kDetSlots + lane] = mine;
+    }
+}
+
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kDetThreads) void render_backward_faces_kernel(const RenderArgs a, const float* __restrict__ boxes)
+{
+    render_backward_faces_body<DIST, ALPHA, RGB, SQ, TEXM>(a, boxes);
+}
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(kThreads) void render_backward_bands_kernel(const RenderArgs a, const float* __restrict__ boxes)
+{
+    render_backward_bands_body<DIST, ALPHA, RGB, SQ, TEXM>(a, boxes);
+}
+
+// the bands of a deferred face, summed in ascending order (one wavefront per face, lane = component) and added to the gradient
+__global__ __launch_bounds__(kThreads) void det_reduce_kernel(const RenderArgs a, int ng)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = min(*a.det_count, kDetBigCap);
+    const int bi = blockIdx.x;
+    if (bi >= n || lane >= ng) return;
+    const int nbands = (a.is + kDetBandRows - 1) / kDetBandRows;
+    const long face_lin = a.det_list[bi];
+    float v = 0.f;
+    for (int band = 0; band < nbands; band++) v += a.det_partial[((long)bi * nbands + band) * kDetSlots + lane];
+    float* dst = lane < 9 ? a.grad_faces + face_lin * 9 + lane : a.grad_textures + face_lin * (ng - 9) + (lane - 9);
+    *dst += v;
 }
 
 // Exhaustive check of sqrt_rn / rcp_rn against the compiler's correctly rounded expansions: every float bit pattern

@@ -106,6 +106,9 @@ def make_params(image_size, background_color, dist_func, dist_scale, dist_square
     p.background_from_buffer = 1 if background_from_buffer else 0
     p.texel_mode = _TEXEL_MODES[os.environ.get('GENDR_TEXEL_MODE', 'reference')]
     p.cull = 0 if os.environ.get('GENDR_CULL', '1') == '0' else 1
+    p.deterministic = 1 if os.environ.get('GENDR_DETERMINISTIC', '0') == '1' else 0
+    p.skip_unlisted_aux = 0
+    p.pool_entries_max = int(os.environ.get('GENDR_POOL_ENTRIES_MAX', '0'))
     return p
 
 
@@ -253,6 +256,8 @@ class GenDRFunction(Function):
             params.clear_ptr = flat.data_ptr()
             params.clear_floats = flat.numel()
             ctx.grad_buffers = (flat, gf, gt)
+        # aggrs_info stays inside this Function (saved for backward, which never looks at tiles no face reaches)
+        params.skip_unlisted_aux = 1 if os.environ.get('GENDR_SKIP_UNLISTED_AUX', '1') != '0' else 0
         soft_colors, aggrs_info, records = native_forward(faces, tex, params)
         params.clear_ptr = None
         params.clear_floats = 0

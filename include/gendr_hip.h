@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GENDR_ABI_VERSION 4
+#define GENDR_ABI_VERSION 5
 
 enum {
     GENDR_OK              = 0,
@@ -66,6 +66,20 @@ typedef struct gendr_params {
                                       gradient buffers of the coming gendr_backward call, which saves that call's
                                       caller a fill launch.  NULL / 0: nothing is cleared.  Honoured by the float32
                                       entry points (gendr_forward, gendr_silhouette_forward, gendr_face_setup) only. */
+    /* ---- ABI 5 ---- */
+    int   deterministic;           /* 1: gendr_backward / gendr_silhouette_backward sum every face's gradient in a fixed
+                                      order (one wavefront per face, no atomics): two calls on the same inputs return
+                                      bit-identical gradients.  The reference's atomicAdd order is not fixed
+                                      (kernel.cu:1054-1063; experiments/train_reconstruction.py:582-586 warns about it).
+                                      Slower; 0 (default): hardware fp32 atomics, one per (tile batch, face, component). */
+    int   skip_unlisted_aux;       /* 1: gendr_forward does not write `aggrs_info` for the 8x8 tiles no face reaches (their
+                                      RGBA is still written).  gendr_backward never reads those pixels' aggrs_info, so the
+                                      autograd path sets it; a caller that hands aggrs_info out (forward_render of
+                                      generalized_renderer_cuda.cpp:74-150) leaves it 0. */
+    unsigned long long pool_entries_max;   /* 0: automatic.  Otherwise an upper limit on the entries of the coverage pool
+                                      (16 bytes each) inside the workspace: tiles that find the pool exhausted are
+                                      rendered exactly all the same by the slower all-faces walk.  gendr_workspace_bytes
+                                      honours it. */
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward

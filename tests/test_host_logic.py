@@ -145,3 +145,33 @@ def test_cull_radius_is_an_upper_bound_for_every_distribution(native_lib):
                         x = float(d * d) if squared else float(d)
                         v = L.gendr_sigmoid_forward(fid, -1.0, x, tau, shape, shift)
                         assert v != v or v <= 1e-6, (fid, tau, squared, shape, shift, float(d), r, v)
+
+
+def test_workspace_of_radiusless_option_sets_has_no_pool(native_lib):
+    """Distributions whose tail never falls below the contribution threshold inside the image (cauchy, reciprocal at the
+    default dist_eps) list every face in every tile: the coverage pool would be its worst case (1.3 GiB at C2, 20 GiB at
+    C4 in round 2) and add nothing -- such option sets get no pool (and no tile masks); and a caller's pool_entries_max
+    caps the pool of any option set."""
+    import ctypes
+    from gendr_amd.functional import renderer as R
+    bg = [0., 0., 0.]
+
+    def ws(B, nf, isz, **kw):
+        o = dict(dist_func='uniform', dist_scale=1e-2, dist_squared=False, dist_shape=None, dist_shift=None, dist_eps=1e4,
+                 aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=None, aggr_rgb_func='softmax', aggr_rgb_eps=1e-3,
+                 aggr_rgb_gamma=1e-3, near=1, far=100, double_side=False, texture_type='surface')
+        limit = kw.pop('pool_entries_max', 0)
+        o.update(kw)
+        p = R.make_params(isz, bg, *[o[k] for k in ('dist_func', 'dist_scale', 'dist_squared', 'dist_shape', 'dist_shift', 'dist_eps',
+                                                   'aggr_alpha_func', 'aggr_alpha_t_conorm_p', 'aggr_rgb_func', 'aggr_rgb_eps',
+                                                   'aggr_rgb_gamma', 'near', 'far', 'double_side', 'texture_type')])
+        p.pool_entries_max = limit
+        return int(native_lib.gendr_workspace_bytes(B, nf, 1, ctypes.byref(p)))
+
+    base = ws(64, 1280, 256)
+    assert base < 200e6                                         # C2: records + masks + pool
+    for dist in ('cauchy', 'reciprocal'):
+        assert ws(64, 1280, 256, dist_func=dist) < 40e6         # records, queues, queue records only
+        assert ws(256, 1280, 512, dist_func=dist) < 200e6       # C4 size: was 20 GiB
+    capped = ws(64, 1280, 256, pool_entries_max=1000)
+    assert capped < base and base - capped > 50e6

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--modes', default='normal,offscreen(scan only),nocull')
+    ap.add_argument('--deterministic', action='store_true', help='gendr_params.deterministic = 1 (per-face backward, no atomics)')
     args = ap.parse_args()
     cfg = B.CONFIGS[args.config]
     Bn = args.batch or cfg['batch']
@@ -51,7 +52,7 @@ def main():
             continue
         if name not in args.modes.split(','):
             continue
-        p = parity.hip_params(isz, o, dict(extra, cull=cull))
+        p = parity.hip_params(isz, o, dict(extra, cull=cull, deterministic=1 if args.deterministic else 0))
         f = fv.clone(); f[..., 0] += shift
         faces = f.reshape(Bn, -1, 9).to(dev).contiguous()
         t = tex.to(dev).contiguous()
