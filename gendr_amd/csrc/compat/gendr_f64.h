@@ -6,15 +6,17 @@
 // option scalars arrive as float exactly as the reference's kernel arguments do, and the few calls the reference makes
 // on explicit float (atanf, kernel.cu:258; expf of the float arguments eps / gamma, :729) stay float.
 //
-// Scope: correctness path for float64 users (gradient checks, conditioning studies), not the tuned path -- one lane
-// per pixel, faces walked in order (wave-uniform loads), the reference's own skip tests only (:747, :769, :784), the
-// gradients leave through global_atomic_add_f64.  The float32 kernels in gendr_kernels.h are the product's hot path.
+// COMPATIBILITY PATH (csrc/compat/), not an MI355X design: one lane per pixel, faces walked in order, the reference's own
+// skip tests only (:747, :769, :784), one fp64 atomic per (pixel, face, component) -- i.e. the reference's algorithm and
+// launch shape, kept so that float64 users (gradient checks, conditioning studies) have the dtype the reference offers.
+// The MI355X-native design (tile queues, coverage entries, pair batches, per-face sums) is the float32 path in
+// gendr_kernels.h; SURVEY 8(b) lists fp64 as optional.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <math.h>
 
-#include "../../include/gendr_hip.h"
+#include "../../../include/gendr_hip.h"
 
 namespace gendr {
 namespace f64 {

@@ -15,7 +15,7 @@
 #include "gendr_voxel.h"
 #include "gendr_texture.h"
 #include "gendr_light.h"
-#include "gendr_f64.h"
+#include "compat/gendr_f64.h"
 
 using namespace gendr;
 

@@ -24,16 +24,36 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_CHECKED = {}          # id(tensor) -> (weakref to the tensor, _version, nv it was checked against)
+
+
 def _check_indices(faces, nv):
     """Range check of the face indices, for error reporting only: the kernels never read outside the vertex
     tensor (an out-of-range index yields NaN vertices and no gradient).  One fused device-side reduction and a
-    single host read; skipped while a HIP graph is being captured (a host read is illegal there).  No cache: a
-    temporary index tensor can reuse the address and version of an earlier one."""
-    if faces.numel() == 0 or (faces.is_cuda and torch.cuda.is_current_stream_capturing()):
+    single host read -- which blocks the host on the stream, so an index tensor is checked ONCE: the result is
+    remembered per tensor OBJECT (a weak reference, so that a new tensor at a recycled address or id is never mistaken for
+    it) and version counter (an in-place edit checks again).  A training loop that projects the same `faces` every step
+    pays the synchronisation on the first step only.  Skipped while a HIP graph is being captured (a host read is illegal
+    there) and with GENDR_CHECK_INDICES=0."""
+    import os
+    import weakref
+    if faces.numel() == 0 or os.environ.get('GENDR_CHECK_INDICES', '1') == '0':
+        return
+    if faces.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    key = id(faces)
+    hit = _CHECKED.get(key)
+    if hit is not None and hit[0]() is faces and hit[1] == faces._version and hit[2] <= nv:
         return
     lo, hi = torch.aminmax(faces)
     if bool((lo < 0) | (hi >= nv)):
         raise IndexError('face index out of range')
+    if len(_CHECKED) > 64:
+        for k in [k for k, v in _CHECKED.items() if v[0]() is None]:
+            del _CHECKED[k]
+        if len(_CHECKED) > 64:
+            _CHECKED.clear()
+    _CHECKED[key] = (weakref.ref(faces), faces._version, nv)
 
 
 class ProjectFacesFunction(torch.autograd.Function):
@@ -48,12 +68,13 @@ class ProjectFacesFunction(torch.autograd.Function):
             raise TypeError('ProjectFacesFunction: float32 vertices only')
         vertices = vertices.contiguous()
         camera = camera.to(torch.float32).contiguous()
+        faces_given = faces                                    # the caller's tensor object: what the index check remembers
         faces = faces.to(torch.int32).contiguous()
         B, nv = vertices.shape[0], vertices.shape[1]
         nf = faces.shape[1]
         if faces.shape[0] not in (1, B) or camera.shape != (B, 12):
             raise ValueError('ProjectFacesFunction: faces must be [B|1,nf,3] and camera [B,12]')
-        _check_indices(faces, nv)
+        _check_indices(faces_given, nv)
         out = torch.empty(B, nf, 3, 3, dtype=torch.float32, device=vertices.device)
         batched = int(faces.shape[0] == B and B > 1)
         with torch.cuda.device(vertices.device):
@@ -93,13 +114,14 @@ class CameraFacesFunction(torch.autograd.Function):
         if vertices.dtype != torch.float32:
             raise TypeError('CameraFacesFunction: float32 vertices only')
         vertices = vertices.contiguous()
+        faces_given = faces                                    # the caller's tensor object: what the index check remembers
         faces = faces.to(torch.int32).contiguous()
         eye, target, up = (t.to(torch.float32).contiguous() for t in (eye, target, up))
         B, nv = vertices.shape[0], vertices.shape[1]
         nf = faces.shape[1]
         if faces.shape[0] not in (1, B) or any(t.shape != (B, 3) for t in (eye, target, up)):
             raise ValueError('CameraFacesFunction: faces must be [B|1,nf,3]; eye, target, up [B,3]')
-        _check_indices(faces, nv)
+        _check_indices(faces_given, nv)
         dev = vertices.device
         camera = torch.empty(B, 12, dtype=torch.float32, device=dev)
         out = torch.empty(B, nf, 3, 3, dtype=torch.float32, device=dev)

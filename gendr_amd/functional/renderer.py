@@ -258,9 +258,11 @@ class GenDRFunction(Function):
             ctx.grad_buffers = (flat, gf, gt)
         # aggrs_info stays inside this Function (saved for backward, which never looks at tiles no face reaches)
         params.skip_unlisted_aux = 1 if os.environ.get('GENDR_SKIP_UNLISTED_AUX', '1') != '0' else 0
-        soft_colors, aggrs_info, records = native_forward(faces, tex, params)
-        params.clear_ptr = None
-        params.clear_floats = 0
+        try:
+            soft_colors, aggrs_info, records = native_forward(faces, tex, params)
+        finally:                               # a failed call must not leave a dangling clear_ptr on the params object
+            params.clear_ptr = None
+            params.clear_floats = 0
         ctx.save_for_backward(faces, tex, soft_colors, records, aggrs_info)
         return soft_colors
 

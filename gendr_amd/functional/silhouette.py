@@ -38,20 +38,24 @@ def _forward(face_vertices, params, target=None, want_grad=False):
         flat = torch.empty(n, dtype=torch.float32, device=dev)
         params.clear_ptr, params.clear_floats = flat.data_ptr(), n
         grad_faces = flat[:B * nf * 9].view(B, nf, 9)
-    isz = params.image_size
-    alpha = torch.empty((B, isz, isz), dtype=torch.float32, device=dev)
-    ws = torch.empty((max(int(L.gendr_silhouette_workspace_bytes(B, nf, ctypes.byref(params))), 256),), dtype=torch.uint8, device=dev)
-    sums = None
-    if target is not None:
-        if tuple(target.shape) != (B, isz, isz):
-            raise ValueError('target must be [B, image_size, image_size] = %s, got %s' % ((B, isz, isz), tuple(target.shape)))
-        target = target.detach().to(device=dev, dtype=torch.float32).contiguous()
-        sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        check(L.gendr_silhouette_forward(_ptr(faces), _ptr(alpha), _ptr(ws), _ptr(target) if target is not None else None,
-                                         _ptr(sums) if sums is not None else None, B, nf, ctypes.byref(params), _stream_ptr()),
-              'gendr_silhouette_forward')
-    params.clear_ptr, params.clear_floats = None, 0
+    try:
+        isz = params.image_size
+        alpha = torch.empty((B, isz, isz), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(int(L.gendr_silhouette_workspace_bytes(B, nf, ctypes.byref(params))), 256),), dtype=torch.uint8, device=dev)
+        sums = None
+        if target is not None:
+            if tuple(target.shape) != (B, isz, isz):
+                raise ValueError('target must be [B, image_size, image_size] = %s, got %s' % ((B, isz, isz), tuple(target.shape)))
+            target = target.detach().to(device=dev, dtype=torch.float32).contiguous()
+            sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gendr_silhouette_forward(_ptr(faces), _ptr(alpha), _ptr(ws), _ptr(target) if target is not None else None,
+                                             _ptr(sums) if sums is not None else None, B, nf, ctypes.byref(params), _stream_ptr()),
+                  'gendr_silhouette_forward')
+    finally:
+        # whatever happened above (a shape error, a failed launch): the caller's params object must not keep a pointer to a
+        # buffer that is about to be freed
+        params.clear_ptr, params.clear_floats = None, 0
     return faces, alpha, ws, target, sums, grad_faces
 
 
@@ -89,8 +93,8 @@ class SilhouetteFunction(Function):
 
 
 class SilhouetteIoUFunction(Function):
-    """(face_vertices, target [B,is,is]) -> sums [B,2] = (sum(alpha t), sum(alpha (1 - t))) per view, and alpha
-    (not differentiable through this output)."""
+    """(face_vertices, target [B,is,is]) -> sums [B,2] = (sum(alpha t), sum(alpha (1 - t))) per view, alpha and the
+    target as the kernel saw it (on the render device, float32) -- neither differentiable through this Function."""
 
     @staticmethod
     def forward(ctx, face_vertices, target, params):
@@ -98,11 +102,12 @@ class SilhouetteIoUFunction(Function):
         ctx.params, ctx.shape, ctx.dtype = params, face_vertices.shape, face_vertices.dtype
         ctx.save_for_backward(faces, alpha, ws, tgt)
         ctx.mark_non_differentiable(alpha)
-        return sums, alpha
+        ctx.mark_non_differentiable(tgt)
+        return sums, alpha, tgt
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_sums, _grad_alpha_unused):
+    def backward(ctx, grad_sums, _grad_alpha_unused, _grad_target_unused):
         faces, alpha, ws, tgt = ctx.saved_tensors
         buf, ctx.grad_faces = ctx.grad_faces, None
         g = _backward(faces, alpha, ws, ctx.params, target=tgt, grad_iou=grad_sums.to(torch.float32).contiguous(), grad_faces=buf)
@@ -125,9 +130,9 @@ def silhouette_iou(face_vertices, target, image_size=256, dist_func='uniform', d
     them (``opt_shape.py:21-23``): intersect = sum(a t), union = sum(a + t - a t) (without the 1e-6)."""
     p = _params(image_size, dist_func, dist_scale, dist_squared, dist_shape, dist_shift, dist_eps,
                 aggr_alpha_func, aggr_alpha_t_conorm_p, near, far)
-    sums, alpha = SilhouetteIoUFunction.apply(face_vertices, target, p)
+    sums, alpha, tgt = SilhouetteIoUFunction.apply(face_vertices, target, p)     # tgt: the target on the render device, float32
     intersect = sums[:, 0]
-    union = target.to(sums.dtype).sum((1, 2)) + sums[:, 1]
+    union = tgt.sum((1, 2)) + sums[:, 1]
     return (intersect, union, alpha) if return_alpha else (intersect, union)
 
 
