@@ -470,19 +470,32 @@ def main():
             dom_bytes = bwd_b * B
             dom_ms = m['bwd_ms']
             achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-            traffic, source = None, None
+            # Profiler figures of the same kernels: HBM traffic (separate rocprofv3 --pmc passes of FETCH_SIZE / WRITE_SIZE) and
+            # the VALU occupation (SQ_ACTIVE_INST_VALU), read from profiles/pmc_<config>.json -- but only if that file was
+            # collected on THESE kernel sources (it carries their hash): a stale file yields null, not a number.
+            traffic, valu_busy, source = None, None, None
             pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.config)
             if os.path.exists(pmc_path):
                 try:
-                    traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch', {}).get(dom)
-                    source = ('profiles/pmc_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the '
-                              'config\'s single-GPU batch (profiles/run_traffic.sh), 2*FETCH+WRITE; not re-measured in this run' % args.config)
+                    from gendr_amd import build as _b
+                    pmc = json.load(open(pmc_path))
+                    if pmc.get('kernel_sha') == _b.source_sha():
+                        traffic = pmc.get('hbm_bytes_per_launch', {}).get(dom)
+                        valu_busy = pmc.get('valu_busy', {}).get(dom)
+                        source = ('profiles/pmc_%s.json (kernel sources %s): rocprofv3 --pmc passes of this command at the config\'s '
+                                  'single-GPU batch (profiles/run_all.sh); traffic = 2*FETCH_SIZE+WRITE_SIZE, valu_busy = '
+                                  'SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * kernel time * 2.4 GHz); not re-measured in this run'
+                                  % (args.config, pmc['kernel_sha']))
+                    else:
+                        source = ('profiles/pmc_%s.json was collected on other kernel sources (%s, now %s): traffic and valu_busy withheld'
+                                  % (args.config, pmc.get('kernel_sha'), _b.source_sha()))
                 except Exception:
                     traffic = None
             out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': source,
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'valu_busy': valu_busy, 'traffic_source': source,
                                'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
-                               'note': 'VALU-bound path (SURVEY.md H2); whole-op fraction on rank 0 = %.4f'
+                               'note': 'VALU-bound path (SURVEY.md H2: report the VALU occupation beside the HBM fraction); '
+                                       'whole-op fraction on rank 0 = %.4f'
                                        % ((fwd_b + bwd_b) * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS)}
             out['kernel_ms'] = {'forward_phase': m['fwd_ms'], 'backward_phase': m['bwd_ms'], 'event_samples': m['n_events']}
         if m['coll_ms'] is not None:
@@ -491,6 +504,33 @@ def main():
                                          % (wl.global_batch, isz, isz)}
         if extra:
             out['extra'] = extra
+        if world == 1 and not args.stub and not args.no_extra and not cfg.get('gather'):
+            # "also report dist_eps = 300" (the training default, train_reconstruction.py:518) -- same
+            # workload, a short second measurement
+            try:
+                cfg300 = dict(cfg, opts=dict(cfg['opts'], dist_eps=300.0))
+                wl300 = Workload(args, cfg300, rank, world, dev, args.scaling)
+                a300 = argparse.Namespace(**dict(vars(args), steps=max(5, args.steps // 3), warmup=2))
+                m300 = measure(a300, wl300, dist, dev)
+                extra['dist_eps_300'] = {'value': wl300.global_batch * a300.steps / m300['elapsed'], 'unit': 'frames/s',
+                                         'ms_per_step': m300['elapsed'] / a300.steps * 1e3, 'steps': a300.steps}
+                del wl300
+            except Exception as e:
+                extra['dist_eps_300'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            sweep = os.path.join(ROOT, 'profiles', 'r03_%s_batch_sweep.json' % args.config)
+            if os.path.exists(sweep):
+                try:
+                    from gendr_amd import build as _b
+                    sw = json.load(open(sweep))
+                    extra['strong_projection'] = {
+                        'speedup_at_n_gpus': sw['strong_projection'], 'ms_per_step_at_batch': sw['batches'],
+                        'current_kernels': sw.get('kernel_sha') == _b.source_sha(),
+                        'note': 'PROJECTION, not a measurement: t(batch 64) / t(batch 64 / N) of this op on ONE MI355X '
+                                '(profiles/r03_%s_batch_sweep.json, tools/batch_sweep.py); no multi-GPU run is behind it' % args.config}
+                except Exception:
+                    pass
+            if extra:
+                out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline and not args.stub:
             nb = min(B, 64)
             tb = cpu_baseline_torch(cfg, wl.fv_cpu[:nb], wl.tex_cpu[:nb])

@@ -72,6 +72,17 @@ def build(force=False, verbose=False, variant="default"):
     return path
 
 
+def source_sha():
+    """Short hash of the kernel sources: stamps the profiler summaries under profiles/ so that bench.py only quotes
+    counters that were collected on THESE kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def build_all(force=False, verbose=False):
     """Every variant, compiled side by side (each hipcc run is single-threaded)."""
     from concurrent.futures import ThreadPoolExecutor

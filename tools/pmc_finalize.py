@@ -1,0 +1,49 @@
+"""Stamps a traffic summary (tools/traffic_summary.py) with the kernel sources' hash and adds the VALU occupation of every
+kernel:   python tools/pmc_finalize.py <pmc_cfg.json> <dir of the SQ counter pass with SQ_ACTIVE_INST_VALU> <kernel_stats.csv>
+valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles, MI355X_MICROARCH.md) * 4 / (1024 SIMDs * average kernel duration * 2.4 GHz)."""
+import collections, csv, glob, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gendr_amd import build
+
+def short(name):
+    name = name.split('(')[0].replace('void ', '').split('<')[0].replace('gendr::', '')
+    return re.sub(r'_w[0-9a-z]$', '', name)
+
+path, sq_dir, stats = sys.argv[1:4]
+d = json.load(open(path))
+acc = collections.defaultdict(list)
+for f in glob.glob(os.path.join(sq_dir, '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == 'SQ_ACTIVE_INST_VALU' and 'gendr' in r['Kernel_Name']:
+            acc[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
+quad = {}
+for k, v in acc.items():
+    g = max(x[0] for x in v)
+    vals = [x[1] for x in v if x[0] == g]
+    quad[k] = sum(vals) / len(vals)
+# kernel durations of the SAME run the counters come from (its kernel trace: same batch, same launches), largest grid only;
+# the bench's kernel_stats.csv is the fallback
+dur = {}
+tr = collections.defaultdict(list)
+for f in glob.glob(os.path.join(sq_dir, '**', '*kernel_trace.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'gendr' in r['Kernel_Name']:
+            g = int(r.get('Grid_Size', 0) or r.get('Grid_Size_X', 0) or 0)
+            tr[short(r['Kernel_Name'])].append((g, (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-3))
+for k, v in tr.items():
+    g = max(x[0] for x in v)
+    vals = sorted(x[1] for x in v if x[0] == g)
+    dur[k] = vals[len(vals) // 2]
+if not dur:
+    for r in csv.DictReader(open(stats)):
+        if 'gendr' in r['Name']:
+            dur[short(r['Name'])] = float(r['AverageNs']) * 1e-3
+d['kernel_sha'] = build.source_sha()
+d['valu_active_quad_cycles'] = quad
+d['avg_kernel_us'] = dur
+d['valu_busy'] = {k: quad[k] * 4 / (1024 * dur[k] * 1e-6 * 2.4e9) for k in quad if k in dur and dur[k] > 0}
+d['valu_busy_note'] = ('SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * median kernel duration in the same counter run * 2.4 GHz nominal clock); '
+                       'the counter run uses the traced batch of profiles/run_all.sh (C4: 32, C5: 8 frames), not the bench batch')
+json.dump(d, open(path, 'w'), indent=1)
+print(json.dumps({k: round(v, 3) for k, v in d['valu_busy'].items()}), d['kernel_sha'])
