@@ -174,7 +174,10 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.tileinfo_off = w.lists_off + align256(tiles * sizeof(int));
     w.entries_off = w.tileinfo_off + align256(tiles * sizeof(int4));
     w.sorted_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
-    w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16 && w.ent_cap8 > 0;   // (no pool: no pair counts to order by)
+    // heavy-first order of the queue records (up to kOrderTilesMax tiles; measured in round 3: skipping it below 8192 tiles,
+    // where every tile could start at once, made batch 8 slower -- 123 vs 108 us per step -- since the sub-tile split puts
+    // more work items than wave slots into the launch); no pool: no pair counts to order by
+    w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16 && w.ent_cap8 > 0;
     w.control_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
     w.ncontrol = kCtlInts;
     // deterministic backward: [count + list of the deferred faces][their band sums]
