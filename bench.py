@@ -21,7 +21,9 @@ step is reported.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline":     algorithmic HBM bytes of the dominant kernel / its measured average duration vs 8 TB/s
   "cpu_baseline": the pure-PyTorch evaluation of the same per-pixel math on all host cores (bounded sample);
-                  "cpu_baseline_oracle" is the C/OpenMP oracle on the same cores.
+                  "cpu_baseline_oracle" is the C/OpenMP oracle on the same cores;
+  "reference_kernels_baseline": the reference's own kernels (oracle/_ref, built from the reference's .cu file by
+                  oracle/build_ref.py) timed on the same GPU on the same workload, when that code object exists.
 """
 import argparse
 import json
@@ -117,6 +119,39 @@ def cpu_baseline_oracle(cfg, fv, tex, target_seconds=12.0):
     return dict(value=n / tn, unit='frames/s', cores=cores, kind='port',
                 sample='%d frame(s) of the same workload (%dx%d, %d faces), forward+backward, C oracle with OpenMP on %d threads, %.1f s'
                        % (n, isz, isz, fvn.shape[1], cores, tn))
+
+
+def gpu_baseline_reference_kernels(cfg, fv, tex, steps=3):
+    """The REFERENCE's own kernels (oracle/_ref: the device half of the reference's generalized_renderer_cuda_kernel.cu
+    compiled for gfx950 by oracle/build_ref.py; test infrastructure, used here only as a reported baseline like the CPU
+    legs) timed on this GPU on the same workload: thread per pixel, every face visited for every pixel, per-pair float
+    atomics -- the design this repository replaces, on the hardware it is replaced on.  None when oracle/_ref was not
+    built.  The build with the compiler's default contraction is timed (what installing the upstream package gives)."""
+    try:
+        from oracle import ref_gpu
+        if not ref_gpu.available():
+            return None
+        from gendr_amd.functional import renderer as R
+        isz = cfg['image_size']
+        o = dict(R_DEFAULTS)
+        o.update(cfg['opts'])
+        o.setdefault('double_side', False)
+        p = R.make_params(isz, [0., 0., 0.], *[o[k] for k in R_KEYS])
+        ms = ref_gpu.time_step(fv.cpu().numpy(), tex.cpu().numpy(), isz, p, steps=steps, warmup=1)
+        B = fv.shape[0]
+        return dict(value=B / ms * 1e3, unit='frames/s', ms_per_step=ms, kind='reference device code on this GPU',
+                    sample='%d steps of the same workload (batch %d, %dx%d, %d faces), forward+backward; the reference\'s '
+                           'kernels from oracle/_ref (clang default contraction), launch shapes of kernel.cu:1099-1222, '
+                           'output buffers re-initialised per step as functional/renderer.py does' % (steps, B, isz, isz, fv.shape[1]))
+    except Exception as e:
+        return dict(error='%s: %s' % (type(e).__name__, e))
+
+
+R_KEYS = ('dist_func', 'dist_scale', 'dist_squared', 'dist_shape', 'dist_shift', 'dist_eps', 'aggr_alpha_func',
+          'aggr_alpha_t_conorm_p', 'aggr_rgb_func', 'aggr_rgb_eps', 'aggr_rgb_gamma', 'near', 'far', 'double_side', 'texture_type')
+R_DEFAULTS = dict(dist_func='uniform', dist_scale=1e-2, dist_squared=False, dist_shape=None, dist_shift=None, dist_eps=1e4,
+                  aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=None, aggr_rgb_func='softmax', aggr_rgb_eps=1e-3,
+                  aggr_rgb_gamma=1e-3, near=1, far=100, double_side=True, texture_type='surface')
 
 
 def _torch_baseline_worker(q, cfg, fv, tex, stride, threads, budget):
@@ -542,6 +577,11 @@ def main():
                 oc['note'] = ('pure-PyTorch baseline failed (%s); C/OpenMP oracle instead' % tb['error']) if tb else \
                              'oracle/torch_ref.py does not cover this option set; C/OpenMP oracle instead'
                 out['cpu_baseline'] = oc
+            rk = gpu_baseline_reference_kernels(cfg, wl.fv_cpu[:nb], wl.tex_cpu[:nb])
+            if rk is not None:
+                out['reference_kernels_baseline'] = rk
+                if 'value' in rk:
+                    rk['speedup_of_this_repo'] = out['value'] / rk['value']
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

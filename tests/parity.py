@@ -74,6 +74,25 @@ def run_oracle(fv, tex, image_size, opts, grad=None, dtype=np.float32, threads=0
     return out
 
 
+def reference_available():
+    from oracle import ref_gpu
+    return ref_gpu.available()
+
+
+def run_reference(fv, tex, image_size, opts, grad=None, dtype=np.float32, variant='gendr_ref_kernels'):
+    """The REFERENCE's own kernels on the GPU (oracle/_ref, built by oracle/build_ref.py from the reference's .cu file;
+    launched by oracle/ref_gpu.py).  Same inputs / outputs as run_oracle.  texel_mode has no meaning here (the reference
+    has one behaviour, the one texel_mode = 0 restates)."""
+    from oracle import ref_gpu
+    o, extra = split_options(opts)
+    assert extra['texel_mode'] == 0, 'the reference has no clamped texel mode'
+    p = hip_params(image_size, o, extra)
+    g = None if grad is None else np.asarray(grad, dtype)
+    out = ref_gpu.render(np.asarray(fv, dtype), np.asarray(tex, dtype), image_size, p, g, dtype, variant=variant,
+                         background=extra['background'] if dtype == np.float64 else None)
+    return out
+
+
 def stats(got, ref, scale=None):
     """max abs error, max / p99 relative error with the denominator floored at 1e-6 * max|ref|
     (or at `scale`, e.g. the sum of |contributions| of a gradient element), fraction above 1e-5."""

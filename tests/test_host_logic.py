@@ -175,3 +175,26 @@ def test_workspace_of_radiusless_option_sets_has_no_pool(native_lib):
         assert ws(256, 1280, 512, dist_func=dist) < 200e6       # C4 size: was 20 GiB
     capped = ws(64, 1280, 256, pool_entries_max=1000)
     assert capped < base and base - capped > 50e6
+
+
+def test_reference_code_object_manifest():
+    """oracle/_ref (the reference's device code, oracle/build_ref.py): when it is built, the manifest names the three
+    kernels of the render path in float and double for both builds, and -- where the reference tree is present --
+    records the hash of the file it was compiled from."""
+    import hashlib
+    import json
+    from oracle import build_ref
+    if not build_ref.available():
+        pytest.skip('oracle/_ref not built')
+    man = json.load(open(build_ref.manifest_path()))
+    assert set(man['variants']) == set(build_ref.VARIANTS)
+    for v in man['variants'].values():
+        assert os.path.exists(os.path.join(build_ref.REF_DIR, v['file']))
+        assert len(v['kernels']) == 6
+        for k in build_ref.KERNELS:
+            assert k + '<float>' in v['kernels'] and k + '<double>' in v['kernels']
+    assert '-ffp-contract=off' in man['variants']['gendr_ref_kernels']['flags']
+    if os.path.exists(build_ref.REF_SOURCE):
+        assert man['reference_sha256'] == hashlib.sha256(open(build_ref.REF_SOURCE, 'rb').read()).hexdigest()
+    # nothing of the translated source stays in the tree
+    assert sorted(os.listdir(build_ref.REF_DIR)) == sorted(['manifest.json'] + [v['file'] for v in man['variants'].values()])
