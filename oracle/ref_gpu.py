@@ -26,8 +26,8 @@ _hip = None
 _modules = {}
 
 
-def available():
-    return build_ref.available()
+def available(name=None):
+    return build_ref.available(name)
 
 
 def _rt():
@@ -47,10 +47,11 @@ def _check(code, what):
 
 
 def _kernels(variant):
-    """variant: 'gendr_ref_kernels' (no contraction: the pin build) or 'gendr_ref_kernels_fma'."""
+    """variant: a code object of oracle/build_ref.py OBJECTS -- 'render' (no contraction: the pin build), 'render_fma',
+    'voxelization', 'load_textures', 'create_texture_image'."""
     if variant not in _modules:
         with open(build_ref.manifest_path()) as f:
-            man = json.load(f)['variants'][variant]
+            man = json.load(f)['objects'][variant]
         torch.cuda.init()
         hip = _rt()
         mod = ctypes.c_void_p()
@@ -64,12 +65,12 @@ def _kernels(variant):
     return _modules[variant][1]
 
 
-def _launch(fn, n_threads, args):
+def _launch(fn, n_threads, args, threads=NUM_THREADS):
     hip = _rt()
-    blocks = (n_threads - 1) // NUM_THREADS + 1
+    blocks = (n_threads - 1) // threads + 1
     arr = (ctypes.c_void_p * len(args))(*[ctypes.cast(ctypes.pointer(a), ctypes.c_void_p) for a in args])
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _check(hip.hipModuleLaunchKernel(fn, blocks, 1, 1, NUM_THREADS, 1, 1, 0, stream, arr, None), 'hipModuleLaunchKernel')
+    _check(hip.hipModuleLaunchKernel(fn, blocks, 1, 1, threads, 1, 1, 0, stream, arr, None), 'hipModuleLaunchKernel')
 
 
 def _ptr(t):
@@ -87,7 +88,7 @@ def _option_args(p, texture_size):
             ctypes.c_float(p.near_), ctypes.c_float(p.far_), ctypes.c_bool(bool(p.double_side)), ctypes.c_int(p.texture_type)]
 
 
-def render(fv, tex, image_size, p, grad=None, dtype=np.float32, variant='gendr_ref_kernels', device='cuda:0', pad_textures=True,
+def render(fv, tex, image_size, p, grad=None, dtype=np.float32, variant='render', device='cuda:0', pad_textures=True,
            background=None):
     """fv [B,nf,3,3], tex [B,nf,T,3] numpy; p: normalised options.  -> dict of numpy arrays (rgba, aggrs_info, faces_info
     and, with `grad` [B,4,is,is], grad_faces / grad_textures), computed by the reference's kernels in `dtype`.
@@ -140,7 +141,7 @@ def render(fv, tex, image_size, p, grad=None, dtype=np.float32, variant='gendr_r
     return out
 
 
-def time_step(fv, tex, image_size, p, steps=10, warmup=2, variant='gendr_ref_kernels_fma', device='cuda:0'):
+def time_step(fv, tex, image_size, p, steps=10, warmup=2, variant='render_fma', device='cuda:0'):
     """ms per forward + backward of the reference's kernels (float) on the given inputs, HIP events around `steps`
     repetitions: the reference's own design timed on the same GPU.  The buffer set-up (zeros / ones) is outside."""
     k = _kernels(variant)
@@ -178,3 +179,98 @@ def time_step(fv, tex, image_size, p, steps=10, warmup=2, variant='gendr_ref_ker
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
+
+
+# ------------------------------------------------------------------------------------------------------------
+# voxelization (voxelization_cuda_kernel.cu) and the texture-atlas kernels: the same arrangement
+# ------------------------------------------------------------------------------------------------------------
+def voxel_sub1(faces, size, dim, device='cuda:0'):
+    """voxelize_sub1 of functional/voxelization.py:11-19 around voxelize_sub1_kernel (launch: voxelization_cuda_kernel.cu
+    :204-217, 512 threads over B * vs * vs rays).  faces [B,nf,3,3] float32 in voxel units -> int32 [B,vs,vs,vs]."""
+    k = _kernels('voxelization')
+    f = torch.from_numpy(np.ascontiguousarray(faces, np.float32)).to(device)
+    B, nf = f.shape[:2]
+    if dim == 0:
+        f = f[:, :, :, [2, 1, 0]].contiguous()
+    elif dim == 1:
+        f = f[:, :, :, [0, 2, 1]].contiguous()
+    vox = torch.zeros(B, size, size, size, dtype=torch.int32, device=device)
+    _launch(k['voxelize_sub1_kernel<float>'], B * size * size, [_ptr(f), _ptr(vox), ctypes.c_int(B), ctypes.c_int(nf), ctypes.c_int(size)], 512)
+    torch.cuda.synchronize()
+    return vox.transpose(dim + 1, -1).contiguous().cpu().numpy()
+
+
+def voxel_sub2(faces, size, device='cuda:0'):
+    k = _kernels('voxelization')
+    f = torch.from_numpy(np.ascontiguousarray(faces, np.float32)).to(device)
+    B, nf = f.shape[:2]
+    vox = torch.zeros(B, size, size, size, dtype=torch.int32, device=device)
+    _launch(k['voxelize_sub2_kernel<float>'], B * nf, [_ptr(f), _ptr(vox), ctypes.c_int(B), ctypes.c_int(nf), ctypes.c_int(size)], 512)
+    torch.cuda.synchronize()
+    return vox.cpu().numpy()
+
+
+def voxel_fill(voxels, device='cuda:0', max_sweeps=100000):
+    """voxelize_sub3 of functional/voxelization.py:29-44: sub3 once, sub4 until the visible count stops changing.
+    voxels int32 [B,vs,vs,vs] (0/1) -> (1 - visible, number of sub4 sweeps)."""
+    k = _kernels('voxelization')
+    vox = torch.from_numpy(np.ascontiguousarray(voxels, np.int32)).to(device)
+    B, vs = vox.shape[0], vox.shape[1]
+    visible = torch.zeros_like(vox)
+    n = B * vs * vs * vs
+    args = [_ptr(vox), _ptr(visible), ctypes.c_int(B), ctypes.c_int(vs)]
+    _launch(k['voxelize_sub3_kernel<float>'], n, args, 512)
+    total = int(visible.sum())
+    sweeps = 0
+    while sweeps < max_sweeps:
+        _launch(k['voxelize_sub4_kernel<float>'], n, args, 512)
+        sweeps += 1
+        now = int(visible.sum())
+        if now == total:
+            break
+        total = now
+    return (1 - visible).cpu().numpy(), sweeps
+
+
+def voxelization(faces, size, normalize=False, device='cuda:0'):
+    """functional/voxelization.py:46-62 with the reference's kernels."""
+    f = np.array(faces, np.float32, copy=True)
+    if not normalize:
+        f *= np.float32(size)
+    v = voxel_sub1(f, size, 0, device) + voxel_sub1(f, size, 1, device) + voxel_sub1(f, size, 2, device) + voxel_sub2(f, size, device)
+    return voxel_fill((v > 0).astype(np.int32), device)[0]
+
+
+def load_textures(image, face_uv, is_update, textures, device='cuda:0'):
+    """load_textures_cuda (load_textures_cuda_kernel.cu:74-107: 1024 threads over numel / 3 texels; texture_res =
+    sqrt(textures.size(1)) converted to size_t).  image [H,W,3], face_uv [nf,3,2], is_update [nf] int32, textures
+    [nf,R*R,3] -> the updated textures."""
+    k = _kernels('load_textures')
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device, dt).contiguous()
+    img, uv, upd, tex = d(image, torch.float32), d(face_uv, torch.float32), d(is_update, torch.int32), d(textures, torch.float32)
+    numel = tex.numel()
+    res = int(math.sqrt(tex.shape[1]))
+    sz = ctypes.c_size_t
+    _launch(k['load_textures_cuda_kernel<float>'], numel // 3, [_ptr(img), _ptr(uv), _ptr(upd), _ptr(tex), sz(numel), sz(res),
+                                                                sz(img.shape[0]), sz(img.shape[1])], 1024)
+    torch.cuda.synchronize()
+    return tex.cpu().numpy()
+
+
+def create_texture_image_kernel(face_uv, textures, image, eps=1e-5, device='cuda:0'):
+    """create_texture_image_cuda (create_texture_image_cuda_kernel.cu:79-111: tile_width = int(sqrt(nf - 1)) + 1,
+    texture_res_out = image.size(1) / tile_width, 1024 threads over numel / 3 pixels).  face_uv [nf,3,2] in pixels,
+    textures [nf,R*R,3], image [rows,cols,3] -> the painted image."""
+    k = _kernels('create_texture_image')
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device).contiguous()
+    uv, tex, img = d(face_uv), d(textures), d(image)
+    nf = tex.shape[0]
+    res_in = int(math.sqrt(tex.shape[1]))
+    tile_width = int(math.sqrt(nf - 1)) + 1
+    res_out = img.shape[1] // tile_width
+    numel = img.numel()
+    sz = ctypes.c_size_t
+    _launch(k['create_texture_image_cuda_kernel<float>'], numel // 3,
+            [_ptr(uv), _ptr(tex), _ptr(img), sz(numel), sz(nf), sz(res_in), sz(res_out), sz(tile_width), ctypes.c_float(eps)], 1024)
+    torch.cuda.synchronize()
+    return img.cpu().numpy()

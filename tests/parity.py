@@ -74,12 +74,12 @@ def run_oracle(fv, tex, image_size, opts, grad=None, dtype=np.float32, threads=0
     return out
 
 
-def reference_available():
+def reference_available(name='render'):
     from oracle import ref_gpu
-    return ref_gpu.available()
+    return ref_gpu.available(name)
 
 
-def run_reference(fv, tex, image_size, opts, grad=None, dtype=np.float32, variant='gendr_ref_kernels'):
+def run_reference(fv, tex, image_size, opts, grad=None, dtype=np.float32, variant='render'):
     """The REFERENCE's own kernels on the GPU (oracle/_ref, built by oracle/build_ref.py from the reference's .cu file;
     launched by oracle/ref_gpu.py).  Same inputs / outputs as run_oracle.  texel_mode has no meaning here (the reference
     has one behaviour, the one texel_mode = 0 restates)."""

@@ -1,6 +1,6 @@
 """The pin: outputs of the REFERENCE's own render kernels, run here, against the CPU restatement and the HIP product.
 
-oracle/_ref/gendr_ref_kernels.co is the device half of /root/reference/gendr/cuda/generalized_renderer_cuda_kernel.cu
+oracle/_ref/gendr_ref_render.co is the device half of /root/reference/gendr/cuda/generalized_renderer_cuda_kernel.cu
 compiled for gfx950 (oracle/build_ref.py: PyTorch-ROCm's own CUDA -> HIP translator for the two includes, clang
 --cuda-device-only, -ffp-contract=off, no file of the reference edited, nothing supplied in place of anything); it
 travels to the GPU box as a built artefact.  oracle/ref_gpu.py launches its kernels with the reference's launch shapes.
@@ -153,7 +153,7 @@ def test_reference_builds_differ_by_contraction(oracle_mod, ref_kernels):
     fv, tex = scenes.slivers(B=1, nf=36)
     grad = _grad(fv, 32, np.float32)
     a = parity.run_reference(fv, tex, 32, {}, grad, np.float32)
-    b = parity.run_reference(fv, tex, 32, {}, grad, np.float32, variant='gendr_ref_kernels_fma')
+    b = parity.run_reference(fv, tex, 32, {}, grad, np.float32, variant='render_fma')
     d = _rel(b['rgba'], a['rgba'])
     print('reference, contraction on vs off: rgba max rel %.3g, differing elements %.2f %%' % (d.max(), 100 * (d > 0).mean()))
     assert np.isfinite(a['rgba']).all()

@@ -178,23 +178,24 @@ def test_workspace_of_radiusless_option_sets_has_no_pool(native_lib):
 
 
 def test_reference_code_object_manifest():
-    """oracle/_ref (the reference's device code, oracle/build_ref.py): when it is built, the manifest names the three
-    kernels of the render path in float and double for both builds, and -- where the reference tree is present --
-    records the hash of the file it was compiled from."""
+    """oracle/_ref (the reference's device code, oracle/build_ref.py): when it is built, the manifest names every kernel
+    of OBJECTS in float and double, the pin build is the one without contraction, and -- where the reference tree is
+    present -- it records the hashes of the files it was compiled from.  Nothing of the translated sources stays."""
     import hashlib
     import json
     from oracle import build_ref
     if not build_ref.available():
         pytest.skip('oracle/_ref not built')
     man = json.load(open(build_ref.manifest_path()))
-    assert set(man['variants']) == set(build_ref.VARIANTS)
-    for v in man['variants'].values():
-        assert os.path.exists(os.path.join(build_ref.REF_DIR, v['file']))
-        assert len(v['kernels']) == 6
-        for k in build_ref.KERNELS:
-            assert k + '<float>' in v['kernels'] and k + '<double>' in v['kernels']
-    assert '-ffp-contract=off' in man['variants']['gendr_ref_kernels']['flags']
-    if os.path.exists(build_ref.REF_SOURCE):
-        assert man['reference_sha256'] == hashlib.sha256(open(build_ref.REF_SOURCE, 'rb').read()).hexdigest()
-    # nothing of the translated source stays in the tree
-    assert sorted(os.listdir(build_ref.REF_DIR)) == sorted(['manifest.json'] + [v['file'] for v in man['variants'].values()])
+    assert set(man['objects']) == set(build_ref.OBJECTS)
+    for name, (src, _, kernels) in build_ref.OBJECTS.items():
+        o = man['objects'][name]
+        assert os.path.exists(os.path.join(build_ref.REF_DIR, o['file'])) and o['source'] == src
+        for k in kernels:
+            assert k + '<float>' in o['kernels'] and k + '<double>' in o['kernels']
+    assert '-ffp-contract=off' in man['objects']['render']['flags']
+    assert '-ffp-contract=off' not in man['objects']['render_fma']['flags']
+    if os.path.isdir(build_ref.REF_CUDA_DIR):
+        for f, sha in man['reference_sha256'].items():
+            assert sha == hashlib.sha256(open(os.path.join(build_ref.REF_CUDA_DIR, f), 'rb').read()).hexdigest()
+    assert sorted(os.listdir(build_ref.REF_DIR)) == sorted(['manifest.json'] + [o['file'] for o in man['objects'].values()])
