@@ -4,8 +4,9 @@ TEST INFRASTRUCTURE ONLY.  Importable from ``tests/``, ``__graft_entry__.smoke``
 and ``bench.py``'s ``cpu_baseline`` leg; the product package ``gendr_amd`` never
 imports this module (a test enforces that).
 
-PARITY UNPINNED: see ``oracle/gendr_oracle.h`` -- the reference has no tests or
-golden vectors for this path and its CUDA-only kernel cannot be built here.
+PARITY PINNED to outputs of the reference's own kernels run on the GPU box
+(``oracle/build_ref.py`` -> ``oracle/_ref``, ``oracle/ref_gpu.py``,
+``tests/test_gpu_reference_pin.py``); see ``oracle/gendr_oracle.h``.
 
 The functions mirror what the reference's Python layer does around the native
 call (``gendr/functional/renderer.py:130-153`` forward allocs and background

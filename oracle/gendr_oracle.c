@@ -1,6 +1,6 @@
 /*
- * gendr_oracle.c -- CPU oracle (test infrastructure only; PARITY UNPINNED,
- * see gendr_oracle.h).  Instantiates gendr_oracle_body.inc for float and
+ * gendr_oracle.c -- CPU oracle (test infrastructure only; pinned to the reference's
+ * own kernels, see gendr_oracle.h).  Instantiates gendr_oracle_body.inc for float and
  * double, the two types AT_DISPATCH_FLOATING_TYPES generates in the reference
  * (kernel.cu:1102,1117,1189), and exports the scalar functions the reference
  * exports through pybind (generalized_renderer_cuda.cpp:233-236).

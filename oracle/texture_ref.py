@@ -4,7 +4,9 @@ gendr_amd/ may import this.
 numpy restatement (fp32 with the reference's double sub-expressions, no contraction) of
   load_textures_cuda_kernel         gendr/cuda/load_textures_cuda_kernel.cu:14-72
   create_texture_image_cuda_kernel  gendr/cuda/create_texture_image_cuda_kernel.cu:16-75
-PARITY UNPINNED by the reference (no tests / vectors for this path; CUDA only).  Pinned instead by closed-form
+PARITY PINNED to outputs of the reference's own kernels (oracle/build_ref.py -> oracle/_ref, oracle/ref_gpu.py): bit for
+bit on the GPU box (tests/test_gpu_reference_pin_aux.py; samples that make the reference read outside its image are left
+to the clamped definition below).  On the CPU side: closed-form
 cases in tests/test_texture_oracle.py (constant images, exact texel centres, atlas round trip).
 Where the reference reads outside its buffers (weight-0 neighbour past the last row / column; texel index outside
 the face's block) the index is clamped, as in the HIP kernels.

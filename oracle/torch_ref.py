@@ -1,6 +1,6 @@
 """Second, independent restatement of the hot path: vectorised pure PyTorch on the CPU.
 
-TEST INFRASTRUCTURE ONLY (same rules as the C oracle; PARITY UNPINNED by the reference, see gendr_oracle.h).
+TEST INFRASTRUCTURE ONLY (same rules as the C oracle; held to the C oracle, which is pinned to the reference's own kernels, see gendr_oracle.h).
 Purpose: (i) cross-check the C oracle with a differently structured implementation (whole-image tensor ops per
 face instead of scalar loops), (ii) BASELINE.json config 1 ("pure-PyTorch CPU per-pixel reference"), (iii) the
 "pure-PyTorch CPU evaluation" bench.py can time next to the GPU number.

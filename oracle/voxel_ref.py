@@ -8,8 +8,9 @@ numpy restatement, stage by stage and in fp32 without contraction, of
   voxelize_sub4_kernel  :148-194                                        (one flood sweep over interior voxels)
   and their driver      gendr/functional/voxelization.py:11-62          (axis permutations, union, sweep-until-stable)
 
-PARITY UNPINNED by the reference: it ships no tests or vectors for this path and its only implementation is CUDA.
-What pins this file: closed-form cases in tests/test_voxel_oracle.py (axis-aligned box, nested shells, open
+PARITY PINNED to outputs of the reference's own kernels (the device half of voxelization_cuda_kernel.cu compiled for gfx950
+by oracle/build_ref.py, launched by oracle/ref_gpu.py): every stage and the whole pipeline agree bit for bit on the GPU box
+(tests/test_gpu_reference_pin_aux.py).  On the CPU side: closed-form cases in tests/test_voxel_oracle.py (axis-aligned box, nested shells, open
 surfaces) and an independent connected-components formulation of the flood fill (scipy.ndimage.label).
 """
 import numpy as np

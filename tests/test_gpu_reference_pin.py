@@ -48,24 +48,8 @@ def _grad(fv, isz, dtype):
     return np.random.RandomState(5).randn(fv.shape[0], 4, isz, isz).astype(dtype)
 
 
-GRAD_FLOOR = 1e-6
-
-
-def _rel(got, ref, scale=None, floor=1e-10):
-    """|got - ref| relative to max(|ref|, scale, 1e-6 of the tensor's largest magnitude, floor).  The absolute floor of
-    the gradients (GRAD_FLOOR; inputs and upstream gradients are O(1), ordinary gradient elements 1 .. 40): where a pixel
-    is covered to 1 - 1e-15, d alpha / d D = (1 - alpha) / (1 - D) is a difference of two doubles that agree in all but
-    their last few bits -- a handful of ulps whose count follows the last bit of exp().  Gradient elements of 1e-15
-    made of such terms alone (logistic tails under hard RGB, single-sided) differ by factors between two libms; they
-    are held to 1e-9 * 1e-6 absolute instead."""
-    got, ref = np.asarray(got, np.float64).reshape(ref.shape), np.asarray(ref, np.float64)
-    d = np.abs(got - ref)
-    d = np.where((got == ref) | (np.isnan(got) & np.isnan(ref)), 0.0, d)
-    mag = np.abs(np.where(np.isfinite(ref), ref, 0.0))
-    if scale is not None:
-        mag = np.maximum(mag, np.asarray(scale, np.float64).reshape(ref.shape))
-    den = np.maximum(mag, max(1e-6 * (float(mag.max()) if mag.size else 0.0), floor))
-    return np.where(np.isnan(d), np.inf, d) / den
+GRAD_FLOOR = parity.GRAD_FLOOR
+_rel = parity.rel_error
 
 
 @pytest.mark.parametrize("scene", ['soup', 'sphere', 'slivers'])

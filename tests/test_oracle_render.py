@@ -150,3 +150,45 @@ def test_oracle_reproduces_golden(oracle_mod, path):
 
 def test_golden_set_is_present():
     assert len(GOLDEN) >= 20
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the pin: vectors computed by the REFERENCE's own kernels (tests/golden/make_reference_golden.py; oracle/_ref on an MI355X)
+# ------------------------------------------------------------------------------------------------------------
+REFERENCE_VECTORS = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference', '*.npz')))
+
+
+@pytest.mark.parametrize("path", REFERENCE_VECTORS, ids=[os.path.basename(p)[:-4] for p in REFERENCE_VECTORS])
+def test_restatement_reproduces_reference_vectors(oracle_mod, path):
+    """Outputs of the reference's kernels (double and float instantiation) on committed inputs: the restatement has to
+    reproduce the double ones to rounding noise (a misread formula, promotion, threshold or traversal order shows at full
+    size there), the face preprocessing bit for bit in both types, and the float ones under the element-wise rule the HIP
+    product is held to (device libm vs glibc)."""
+    import criteria
+    z = np.load(path)
+    name = os.path.basename(path)[:-4]
+    opts = json.loads(str(z['options']))
+    isz = int(z['image_size'])
+    fv, tex, grad = z['fv'], z['tex'], z['grad']
+    c = parity.run_oracle(fv.astype(np.float64), tex.astype(np.float64), isz, opts, grad.astype(np.float64), np.float64)
+    assert np.array_equal(c['faces_info'], z['f64_faces_info'], equal_nan=True)
+    # cauchy evaluates atanf in FLOAT whatever scalar_t is (kernel.cu:258): device and glibc results differ in the last bit
+    tol = 5e-5 if opts.get('dist_func') == 'cauchy' else 1e-9
+    for k in ('rgba', 'aggrs_info'):
+        assert parity.rel_error(z['f64_' + k], c[k]).max() <= tol, k
+    for k, ak in (('grad_faces', 'abs_faces'), ('grad_textures', 'abs_textures')):
+        assert parity.rel_error(z['f64_' + k], c[k], scale=c[ak], floor=parity.GRAD_FLOOR).max() <= max(tol, 1e-8), k
+    ref32 = {k: z['f32_' + k] for k in ('rgba', 'aggrs_info', 'grad_faces', 'grad_textures')}
+    c32 = parity.run_oracle(fv, tex, isz, opts, grad, np.float32)
+    assert np.array_equal(c32['faces_info'], z['f32_faces_info'], equal_nan=True)
+    if criteria.alpha_is_algebraic(name):
+        assert np.array_equal(c32['rgba'][:, 3], ref32['rgba'][:, 3], equal_nan=True)
+    bad, _, _ = criteria.check_case(fv, tex, isz, opts, ref32, grad, oracle_f32=c32)
+    assert not bad, bad
+
+
+def test_reference_vector_set_is_present():
+    assert len(REFERENCE_VECTORS) >= 29
+    z = np.load(REFERENCE_VECTORS[0])
+    made = json.loads(str(z['produced_by']))
+    assert '-ffp-contract=off' in made['flags'] and 'generalized_renderer_cuda_kernel.cu' in made['reference_sha256']

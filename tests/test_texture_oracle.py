@@ -1,5 +1,5 @@
 """The texture-atlas oracle (oracle/texture_ref.py) against closed-form cases.  (The reference has no vectors for
-this path: parity unpinned by it.)"""
+this path: the pin to its own kernels is tests/test_gpu_reference_pin_aux.py.)"""
 import numpy as np
 
 from oracle import texture_ref as T

@@ -119,3 +119,29 @@ def test_baseline_config1_unit_quad():
     assert float(a.max()) == 1.0 and float(a.min()) == 0.0
     assert abs(float(a.sum()) - (32 * 32 - 32 * 0.25)) < 1e-4
     assert out['rgba'].shape == (1, 4, 64, 64) and out['aggrs_info'].shape == (1, 2, 64, 64)
+
+
+_REFERENCE_VECTORS = sorted(__import__('glob').glob(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)),
+                                                                              'golden', 'reference', '*.npz')))
+
+
+@pytest.mark.parametrize("path", _REFERENCE_VECTORS, ids=[p.split('/')[-1][:-4] for p in _REFERENCE_VECTORS])
+def test_torch_restatement_reproduces_reference_vectors_f64(path):
+    """The second restatement against outputs of the reference's own kernels (tests/golden/make_reference_golden.py),
+    float64: independent of the C oracle."""
+    import json
+    z = np.load(path)
+    opts = json.loads(str(z['options']))
+    isz = int(z['image_size'])
+    kw = {k: v for k, v in opts.items() if k != 'T'}
+    t = torch_ref.render(torch.from_numpy(z['fv'].astype(np.float64)), torch.from_numpy(z['tex'].astype(np.float64)), isz,
+                         grad=torch.from_numpy(z['grad'].astype(np.float64)), **kw)
+    tol = 5e-5 if opts.get('dist_func') == 'cauchy' else 1e-7
+    for k in ('rgba', 'aggrs_info'):
+        assert parity.rel_error(t[k].numpy(), z['f64_' + k]).max() <= tol, k
+    for k in ('grad_faces', 'grad_textures'):
+        ref = z['f64_' + k]
+        e = parity.rel_error(t[k].numpy().reshape(ref.shape), ref, floor=parity.GRAD_FLOOR)
+        # no per-element sum of magnitudes here: measured against the tensor's largest element
+        cauchy = opts.get('dist_func') == 'cauchy'            # float atanf under cancellation
+        assert e.max() <= (5e-3 if cauchy else 1e-4) and np.percentile(e, 99) <= max(tol, 1e-7) * 10, (k, float(e.max()))

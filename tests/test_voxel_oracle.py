@@ -1,5 +1,5 @@
 """The voxelization oracle (oracle/voxel_ref.py) against closed-form cases and an independent formulation of
-its flood fill.  (The reference has no vectors for this path: parity unpinned by it.)"""
+its flood fill.  (The reference has no vectors for this path; the pin to its own kernels is tests/test_gpu_reference_pin_aux.py.)"""
 import numpy as np
 from scipy import ndimage
 
