@@ -1,8 +1,8 @@
 """Regenerates tests/golden/*.npz.
 
-IMPORTANT: these vectors come from THIS repo's CPU oracle (oracle/), not from the reference: the reference
-(CUDA only, no tests, no fixtures) cannot be executed in the build image, so parity is unpinned by it
-(DESIGN.md).  The files pin the oracle itself against accidental change and give the GPU tests fixed
+IMPORTANT: these vectors come from THIS repo's CPU oracle (oracle/), not from the reference (vectors computed by the
+reference's own kernels are in tests/golden/reference/, see make_reference_golden.py).  The files here pin the oracle
+itself against accidental change and give the GPU tests fixed
 known-answer inputs/outputs that do not depend on the oracle being rebuilt on the GPU box.
 
     python tests/golden/make_golden.py

@@ -7,7 +7,9 @@ size (one frame each), per tensor: max / p99 relative error, fraction above 1e-5
 aggrs_info and the gradients, for BOTH build variants (default: fp32-accurate gradient side; exact: the reference's
 rounding, -DGENDR_EXACT_GRADIENT=1), the report of the element-wise acceptance rule (tests/criteria.py: violations, how
 many elements are not held to 1e-5 and why), the conditioned gradient error (error / sum of |contributions|), default
-vs exact directly, and whether the culled traversal is bit-identical to the all-pairs one."""
+vs exact directly, whether the culled traversal is bit-identical to the all-pairs one, and -- when oracle/_ref is built --
+the same inputs through the REFERENCE's own kernels: the HIP product and the restatement against their float output
+(element-wise rule), the restatement against their double output (maximum relative deviation)."""
 import json
 import os
 import subprocess
@@ -55,6 +57,28 @@ def one_case(fv, tex, isz, opts, with_cull_check=True, n_jitter=len(criteria.JIT
     entry['oracle_fp32_vs_fp64'] = dict(rgba=parity.stats(o32['rgba'], refs['o64']['rgba']),
                                         grad_faces_cond=parity.stats(o32['grad_faces'], refs['o64']['grad_faces'], scale=refs['o64']['abs_faces']))
     entry['accepted'] = all(e['accepted'] for e in entry['variants'].values())
+    if parity.reference_available() and parity.split_options(opts)[1]['texel_mode'] == 0:
+        # the pin: the REFERENCE's own kernels (oracle/_ref) on the same inputs
+        r32 = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
+        r64 = parity.run_reference(fv, tex, isz, opts, grad, np.float64)
+        o64 = refs['o64']
+        pinned = dict(refs, o32=dict(r32, abs_faces=o32['abs_faces'], abs_textures=o32['abs_textures'],
+                                     grad_faces=r32['grad_faces'].reshape(o32['grad_faces'].shape)))
+        rep = criteria.elementwise(hips['default'], pinned)
+        rep_o = criteria.elementwise(o32, pinned)
+        entry['reference_kernels'] = dict(
+            hip_vs_reference_f32=dict(elementwise=rep, accepted=not criteria.failures(rep), failures=criteria.failures(rep),
+                                      rgba=parity.stats(hips['default']['rgba'], r32['rgba']),
+                                      grad_faces_cond=parity.stats(hips['default']['grad_faces'], r32['grad_faces'].reshape(o32['grad_faces'].shape), scale=o32['abs_faces'])),
+            restatement_vs_reference_f32=dict(accepted=not criteria.failures(rep_o), failures=criteria.failures(rep_o),
+                                              faces_info_identical=bool(np.array_equal(o32['faces_info'], r32['faces_info'], equal_nan=True)),
+                                              rgba=parity.stats(o32['rgba'], r32['rgba'])),
+            restatement_vs_reference_f64=dict(
+                faces_info_identical=bool(np.array_equal(o64['faces_info'], r64['faces_info'], equal_nan=True)),
+                rgba_max=float(parity.rel_error(r64['rgba'], o64['rgba']).max()),
+                aggrs_info_max=float(parity.rel_error(r64['aggrs_info'], o64['aggrs_info']).max()),
+                grad_faces_max=float(parity.rel_error(r64['grad_faces'], o64['grad_faces'], scale=o64['abs_faces'], floor=parity.GRAD_FLOOR).max()),
+                grad_textures_max=float(parity.rel_error(r64['grad_textures'], o64['grad_textures'], scale=o64['abs_textures'], floor=parity.GRAD_FLOOR).max())))
     if with_cull_check:
         h, h2 = hips['default'], parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
         entry['cull_identical'] = bool(all(np.array_equal(h[k], h2[k], equal_nan=True) for k in ('rgba', 'aggrs_info')))
@@ -71,6 +95,12 @@ def short(name, entry):
                                                                e['grad_faces_cond']['p99_rel'], e['grad_faces_cond']['frac_gt_1e5']))
     parts.append('d-vs-e %.1e' % entry['default_vs_exact']['grad_faces']['max_rel'])
     parts.append('rgba max %.1e' % entry['rgba']['max_rel'])
+    rk = entry.get('reference_kernels')
+    if rk:
+        f = rk['restatement_vs_reference_f64']
+        parts.append('ref-kernels: hip %s, oracle f32 %s, f64 rgba %.1e gf %.1e' % (
+            'ok' if rk['hip_vs_reference_f32']['accepted'] else 'REJECTED', 'ok' if rk['restatement_vs_reference_f32']['accepted'] else 'REJECTED',
+            f['rgba_max'], f['grad_faces_max']))
     return ' | '.join(parts)
 
 
@@ -114,6 +144,18 @@ def main():
                        grad_faces_cond_over_1e5_max=sum(1 for e in es if e['grad_faces_cond']['max_rel'] > 1e-5),
                        grad_faces_cond_over_1e5_p99=sum(1 for e in es if e['grad_faces_cond']['p99_rel'] > 1e-5))
     summ['default_vs_exact_grad_faces_max'] = max(c['default_vs_exact']['grad_faces']['max_rel'] for c in cases)
+    pinned = [c['reference_kernels'] for c in cases if 'reference_kernels' in c]
+    if pinned:
+        non_cauchy = [c['reference_kernels'] for k, c in list(out['matrix'].items()) + list(out['full_size'].items())
+                      if 'reference_kernels' in c and 'cauchy' not in k]
+        summ['reference_kernels'] = dict(
+            what="the reference's own kernels (oracle/_ref, oracle/build_ref.py) run on this GPU on the same inputs",
+            cases=len(pinned),
+            hip_accepted_f32=sum(1 for r in pinned if r['hip_vs_reference_f32']['accepted']),
+            restatement_accepted_f32=sum(1 for r in pinned if r['restatement_vs_reference_f32']['accepted']),
+            faces_info_identical=sum(1 for r in pinned if r['restatement_vs_reference_f32']['faces_info_identical'] and r['restatement_vs_reference_f64']['faces_info_identical']),
+            restatement_f64_rgba_max_without_cauchy=max(r['restatement_vs_reference_f64']['rgba_max'] for r in non_cauchy),
+            restatement_f64_grad_faces_max_without_cauchy=max(r['restatement_vs_reference_f64']['grad_faces_max'] for r in non_cauchy))
     out['summary'] = summ
     os.makedirs('gpurun_out', exist_ok=True)
     path = 'gpurun_out/parity_%s.json' % tag

@@ -1,7 +1,8 @@
 """The oracle's scalar functions against independent closed forms (scipy), and the product's host scalar
 exports against the oracle.  CPU only.
 
-The reference holds no tests or golden vectors for this path (parity unpinned); these checks pin the
+The reference holds no tests or golden vectors for this path (the pin to outputs of its own kernels is
+tests/golden/reference + tests/test_gpu_reference_pin.py); these checks additionally hold the
 restated CDFs / pdfs to the published definitions of the distributions and the
 t-conorms to their algebraic identities (appendix B)."""
 import math
