@@ -87,6 +87,9 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 #define GENDR_T(i) do {} while (0)
 #endif
 
+#ifndef GENDR_EXP_KNOWN
+#define GENDR_EXP_KNOWN 0
+#endif
 #ifndef GENDR_ABLATE
 #define GENDR_ABLATE 0   // diagnostic builds only (tools/): 1..3 cut the forward loop short after a stage
 #endif
@@ -867,6 +870,36 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp,
     return true;
 }
 
+// The same closest-point evaluation for a pair whose edge is already known (backward: the forward kernel recorded, per
+// pair, which edge point_to_face() selected): one edge instead of three candidates resp. the corner logic, the very
+// expressions of the two branches above on the very operands (inside: t, 1 - t unclamped, :99-105; outside: clamped, :150-158).
+__device__ __forceinline__ void point_to_face_edge(Pair& q, const float* r, int e)
+{
+    const float w0 = q.w0, w1 = q.w1, w2 = q.w2;
+    const float x0 = r[kRecXY + 0], y0 = r[kRecXY + 1], x1 = r[kRecXY + 2], y1 = r[kRecXY + 3],
+                x2 = r[kRecXY + 4], y2 = r[kRecXY + 5];
+    const bool inside = w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1;
+    const bool e0 = e == 0, e1 = e == 1;
+    const float E00 = r[kRecEdge + 0], E01 = r[kRecEdge + 1], E02 = r[kRecEdge + 2];
+    const float E10 = r[kRecEdge + 3], E11 = r[kRecEdge + 4], E12 = r[kRecEdge + 5];
+    const float E20 = r[kRecEdge + 6], E21 = r[kRecEdge + 7], E22 = r[kRecEdge + 8];
+    const double D0 = rec_double(r, kRecRDen + 0), D1 = rec_double(r, kRecRDen + 2), D2 = rec_double(r, kRecRDen + 4);
+    const float A0 = e0 ? E00 : (e1 ? E10 : E20);
+    const float A1 = e0 ? E01 : (e1 ? E11 : E21);
+    const float A2 = e0 ? E02 : (e1 ? E12 : E22);
+    const float Av1 = e0 ? A1 : (e1 ? A2 : A0);
+    const double rden = e0 ? D0 : (e1 ? D1 : D2);
+    const float tv = div_by(w0 * A0 + w1 * A1 + w2 * A2 - Av1, rden);
+    const float ta = inside ? tv : fminf(fmaxf(tv, 0.f), 1.f);
+    const float tb = inside ? 1 - tv : fminf(fmaxf(1 - tv, 0.f), 1.f);
+    q.t0 = (e0 ? ta : (e1 ? 0.f : tb)) - w0;
+    q.t1 = (e0 ? tb : (e1 ? ta : 0.f)) - w1;
+    q.t2 = (e0 ? 0.f : (e1 ? tb : ta)) - w2;
+    q.dx = q.t0 * x0 + q.t1 * x1 + q.t2 * x2;
+    q.dy = q.t0 * y0 + q.t1 * y1 + q.t2 * y2;
+    q.sign = inside ? 1.f : -1.f;
+}
+
 __device__ __forceinline__ bool inside_closed(const Pair& q)
 {
     return q.w0 <= 1 && q.w0 >= 0 && q.w1 <= 1 && q.w1 >= 0 && q.w2 <= 1 && q.w2 >= 0;   // :62-64
@@ -892,13 +925,17 @@ __device__ __forceinline__ void barycentrics(Pair& q, const float* r, float xp, 
 // stage 2 on r[16..34): soft fragment of a pair whose pixel is inside the box.  Returns true if the pair
 // contributes (none of the skips at :769, :784 fires).
 template <int DIST, int SQ>
-__device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp, float yp, const RenderArgs& a, const DistParams& dp)
+__device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp, float yp, const RenderArgs& a, const DistParams& dp, int edge = -1)
 {
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     if (dist == kHeaviside) {
         q.sign = 0.f; q.dx = 0.f; q.dy = 0.f; q.dis = 0.f; q.t0 = q.t1 = q.t2 = 0.f;
         q.frag = inside_closed(q) ? 1.f : 0.f;                                      // :762-764
     } else {
+#if GENDR_EXP_KNOWN
+        if (edge >= 0) point_to_face_edge(q, r, edge);
+        else
+#endif
         if (!point_to_face(q, r, xp, yp)) return false;
         float dis = q.dx * q.dx + q.dy * q.dy;                                      // :768
         if (q.sign < 0 && dis >= a.thr) return false;                               // :769
@@ -1631,7 +1668,11 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
     // the final select back into such a default).
     float C_xy = 0.f, zp = 0.f;
     float wc[3];
+#if GENDR_EXP_KNOWN
+    bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp, PRELOADED ? -1 : (int)((unsigned)(fn + (int)(px.xp * 1024.f)) % 3u));
+#else
     bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp);
+#endif
     if (live) {
         // alpha only, and this face's depth cannot fail the near / far test (see face_setup_kernel): no depth stage
         const bool need_depth = !(kSil && (__float_as_int(r[kRecBits]) & kBitDepthSafe));

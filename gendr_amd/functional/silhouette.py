@@ -101,8 +101,7 @@ class SilhouetteIoUFunction(Function):
         faces, alpha, ws, tgt, sums, ctx.grad_faces = _forward(face_vertices, params, target, want_grad=ctx.needs_input_grad[0])
         ctx.params, ctx.shape, ctx.dtype = params, face_vertices.shape, face_vertices.dtype
         ctx.save_for_backward(faces, alpha, ws, tgt)
-        ctx.mark_non_differentiable(alpha)
-        ctx.mark_non_differentiable(tgt)
+        ctx.mark_non_differentiable(alpha, tgt)     # one call: a second call would replace the first one's set
         return sums, alpha, tgt
 
     @staticmethod

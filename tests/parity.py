@@ -90,6 +90,13 @@ def run_reference(fv, tex, image_size, opts, grad=None, dtype=np.float32, varian
     g = None if grad is None else np.asarray(grad, dtype)
     out = ref_gpu.render(np.asarray(fv, dtype), np.asarray(tex, dtype), image_size, p, g, dtype, variant=variant,
                          background=extra['background'] if dtype == np.float64 else None)
+    if int(p.dist_func) == 0 and out.get('grad_faces') is not None:
+        # Heaviside backward: the reference multiplies UNINITIALISED locals by D' = 0 (kernel.cu:926-933, :1034-1051; DESIGN
+        # quirk i) -- exactly 0 whenever the stale registers hold finite values, NaN when they do not, which depends on what
+        # ran on the CU before (seen: the same case passes alone and fails inside the whole suite).  The defined value is 0.
+        gf = out['grad_faces'].reshape(-1, 3, 3)
+        xy = gf[:, :, :2]
+        xy[~np.isfinite(xy)] = 0
     return out
 
 
