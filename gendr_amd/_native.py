@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GendrParams(ctypes.Structure):
@@ -42,6 +42,8 @@ class GendrParams(ctypes.Structure):
         ("deterministic", ctypes.c_int),
         ("skip_unlisted_aux", ctypes.c_int),
         ("pool_entries_max", ctypes.c_ulonglong),
+        ("pair_hints", ctypes.c_int),
+        ("reserved_", ctypes.c_int),
     ]
 
 

@@ -120,8 +120,9 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" float gendr_cull_radius(const gendr_params* p);
 
 struct Workspace {
-    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, sorted_off, control_off, det_off, total;
+    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, hints_off, sorted_off, control_off, det_off, total;
     bool ordered;              // the render kernels walk the heavy-first copy of the queue records (order_tiles_kernel)
+    bool hints;                // the forward kernel leaves pair hints for the backward kernel (gendr_params::pair_hints)
     int tiles_x, chunks, supers_x, ncontrol;
     long ent_cap8;
 };
@@ -154,8 +155,20 @@ long entry_capacity(long B, long tiles, long nf, const gendr_params* p)
     return ((long)want + 7) / 8 * 8;
 }
 
+// gendr_params::pair_hints.  Automatic: on while the cull radius stays within kHintRadiusPx pixels -- the hints save the
+// backward kernel the closest-point search (C2 -8.5 us of 104, C3 -6 %, C5 -7 %) and cost the forward kernel 3-4 % (C2 +3 us);
+// with long tails (C4: 37 pixels) the backward kernel is not bound by its vector arithmetic and gains nothing.
+constexpr float kHintRadiusPx = 16.f;
+bool pair_hints_enabled(const gendr_params* p)
+{
+    if (!GENDR_PAIR_HINTS || p->pair_hints < 0 || !p->cull) return false;
+    if (p->pair_hints > 0) return true;
+    const float r = gendr_cull_radius(p);
+    return r * (float)p->image_size * 0.5f <= kHintRadiusPx;
+}
+
 // workspace layout: [bin records B*nf*16 f32][face records B*nf*REC f32][tile masks B*tiles*chunks u64]
-//                   [tile queues B*tiles i32][queue records B*tiles 4 x i32][entry pool]
+//                   [tile queues B*tiles i32][queue records B*tiles 4 x i32][entry pool][pair hints, one slot per entry slot]
 //                   [heavy-first copy of the queue records, up to kOrderTilesMax tiles][control counters]
 Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
 {
@@ -173,7 +186,10 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.lists_off = w.masks_off + (w.ent_cap8 > 0 ? align256(tiles * w.chunks * sizeof(unsigned long long)) : 0);
     w.tileinfo_off = w.lists_off + align256(tiles * sizeof(int));
     w.entries_off = w.tileinfo_off + align256(tiles * sizeof(int4));
-    w.sorted_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
+    // pair hints of the forward kernel for the backward kernel, one 16-byte slot per entry slot (PairHints in gendr_kernels.h)
+    w.hints_off = w.entries_off + align256((size_t)w.ent_cap8 * 8 * sizeof(CoverEnt));
+    w.hints = pair_hints_enabled(p) && w.ent_cap8 > 0;
+    w.sorted_off = w.hints_off + (w.hints ? align256((size_t)w.ent_cap8 * 8 * sizeof(PairHints)) : 0);
     // heavy-first order of the queue records (up to kOrderTilesMax tiles; measured in round 3: skipping it below 8192 tiles,
     // where every tile could start at once, made batch 8 slower -- 123 vs 108 us per step -- since the sub-tile split puts
     // more work items than wave slots into the launch); no pool: no pair counts to order by
@@ -228,6 +244,7 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.tile_info = w.ordered ? reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.sorted_off) : a.tile_info_raw;
     a.entries = reinterpret_cast<CoverEnt*>(static_cast<char*>(const_cast<void*>(workspace)) + w.entries_off);
     a.ent_cap8 = w.ent_cap8;
+    a.hints = w.hints ? reinterpret_cast<PairHints*>(static_cast<char*>(const_cast<void*>(workspace)) + w.hints_off) : nullptr;
     a.textures = textures;
     a.B = B; a.nf = nf; a.T = T;
     a.R = (int)sqrt((double)T);                                  // kernel.cu:1098

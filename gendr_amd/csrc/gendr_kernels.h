@@ -87,8 +87,8 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 #define GENDR_T(i) do {} while (0)
 #endif
 
-#ifndef GENDR_EXP_KNOWN
-#define GENDR_EXP_KNOWN 0
+#ifndef GENDR_PAIR_HINTS
+#define GENDR_PAIR_HINTS 1   // 0: no pair hints from the forward to the backward kernel (A/B builds)
 #endif
 #ifndef GENDR_ABLATE
 #define GENDR_ABLATE 0   // diagnostic builds only (tools/): 1..3 cut the forward loop short after a stage
@@ -199,6 +199,24 @@ constexpr int kBinRec = 16;
 // tests for it (bit p = pixel lane p).  Written by cover_kernel, read by both render kernels.
 struct __attribute__((aligned(16))) CoverEnt { int fn; int npix; unsigned lo, hi; };
 
+// Pair hints: what the forward kernel found out about the 64 pairs of a batch and the backward kernel would otherwise have to
+// find out again -- two bits per pair (bit l of `lo` / `hi` = pair lane l): 0, 1, 2 = the edge of the face the closest-point
+// search selected (the minimum over three candidates for a pixel inside the face, the corner logic of kernel.cu:120-142
+// outside); kHintDead = the pair gets no gradient (it failed one of the skip tests :769 / :784, or its barycentrics are
+// NaN; the depth test :810 / :994 is repeated by backward, which needs the depth anyway).  Backward evaluates one edge with point_to_face_edge() instead of the whole search -- the same
+// float operations on the same operands for that edge, so every value downstream is bit for bit the forward kernel's.
+// A tile's batches are windows of 64 consecutive codes of its pair list, so batch k is the same set of pairs in both
+// kernels as long as neither splits the tile among several waves (walk_split_log2); the forward kernel says so per queue
+// in the control block (kCtlHintFlag), and face_setup_kernel clears that word with the rest of the block on every call,
+// so hints of an earlier call are never taken for this one's.  A tile has at most as many batches as entries (an entry
+// holds 1..64 pairs), hence the parallel indexing.
+struct __attribute__((aligned(16))) PairHints { unsigned long long lo, hi; };
+constexpr int kHintDead = 3;
+// control[x * kCtlStride + kCtlHintFlag]: OR of 1 (the forward kernel rendered queue x unsplit and wrote the hints of its
+// tiles) and 2 (some pair of the queue cannot be described by a hint -- the inside branch selected no edge, kHintNone, which
+// takes NaN or infinite candidates on a degenerate face -- backward then repeats the whole search for that queue)
+constexpr int kCtlHintFlag = 1;
+
 __device__ __forceinline__ long queue_begin(int x, long n_tiles) { return ((long)x * n_tiles) >> 3; }
 // the x with queue_begin(x) <= g < queue_begin(x + 1)
 __device__ __forceinline__ int queue_of_tile(long g, long n_tiles) { return (int)min(7L, (8 * (g + 1) + n_tiles - 1) / n_tiles - 1); }
@@ -226,6 +244,7 @@ struct RenderArgs {
                                 //   kernels then run the per-pixel tests themselves from the mask row), the entry count
                                 //   pair count from cover_kernel: one scalar load tells a wave all it needs
     long          ent_cap8;     // capacity of one region of the entry pool
+    PairHints*    hints;        // parallel to `entries`: slot (tile's first entry + k) = the hints of the tile's k-th batch of 64 pairs
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
     int*   det_count;           // deterministic backward: number of deferred (large-box) faces, their list, their band sums
@@ -726,7 +745,7 @@ struct TileCtx {
 // The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
 // own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
 // tiles list a face) that is one tile per wave and no wave is launched in vain.
-struct TileWalk { long qbase, qend; int total, empties, rank, next, stride, split_log2; };
+struct TileWalk { long qbase, qend; int total, empties, rank, next, stride, split_log2, hint_flag; };
 
 // Sub-tile split of the render kernels.  The latency of a launch is the latency of one wave on the heaviest tile (ten
 // batches at the headline scene); when a queue lists fewer tiles than the chip holds waves for it at once (resident_q, from
@@ -760,6 +779,7 @@ __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int 
     w.qend = queue_begin(xcd + 1, a.total_tiles);
     w.total = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride]);
     w.empties = __builtin_amdgcn_readfirstlane(a.control[(8 + xcd) * kCtlStride]);
+    w.hint_flag = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride + kCtlHintFlag]);
     w.stride = (int)(gridDim.x >> 3) * waves_per_block;
     w.rank = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * waves_per_block + (int)(threadIdx.x >> 6));
     w.next = w.rank;
@@ -790,7 +810,19 @@ struct Pair {
     float w0, w1, w2;        // barycentrics (:39-43)
     float t0, t1, t2;        // t - w of the closest boundary point (:103-105,:157)
     float sign, dx, dy, dis, frag;
+    float hint;              // the edge point_to_face() selected, as a float the forward kernel's ballots can test with ONE compare
+                             // against an inline constant each (no register for a mask or a literal -- the forward kernel has
+                             // none to spare): kHintEdge0 / 1 / 2, or kHintNone when the inside branch selected none of its
+                             // candidates (:112 never true).  A pair without a gradient keeps hint = +0.
 };
+#define kHintEdge0 1.0f
+#define kHintEdge1 (-1.0f)
+#define kHintEdge2 4.0f
+#define kHintNone  __builtin_nanf("")
+// bit 0 of the 2-bit code (edge 1, or dead = 3): hint <= 0;  bit 1 (edge 2, or dead): |hint| <> 1 (ordered);  none: unordered
+__device__ __forceinline__ bool hint_bit0(float h) { return h <= 0.f; }
+__device__ __forceinline__ bool hint_bit1(float h) { const float m = __builtin_fabsf(h); return m < 1.f || m > 1.f; }
+__device__ __forceinline__ bool hint_none(float h) { return h != h; }
 
 __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 
@@ -817,10 +849,10 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp,
         const float cd = cdx * cdx + cdy * cdy;
         // running strict minimum in edge order 0,1,2 starting from 1e8 (:86,:112)
         float best = 100000000.f;
-        q.dx = 0.f; q.dy = 0.f; q.t0 = 0.f; q.t1 = 0.f; q.t2 = 0.f;
-        if (ad < best) { best = ad; q.dx = adx; q.dy = ady; q.t0 = a0; q.t1 = a1; q.t2 = a2; }
-        if (bd < best) { best = bd; q.dx = bdx; q.dy = bdy; q.t0 = b0; q.t1 = b1; q.t2 = b2; }
-        if (cd < best) { best = cd; q.dx = cdx; q.dy = cdy; q.t0 = c0; q.t1 = c1; q.t2 = c2; }
+        q.dx = 0.f; q.dy = 0.f; q.t0 = 0.f; q.t1 = 0.f; q.t2 = 0.f; q.hint = kHintNone;
+        if (ad < best) { best = ad; q.dx = adx; q.dy = ady; q.t0 = a0; q.t1 = a1; q.t2 = a2; q.hint = kHintEdge0; }
+        if (bd < best) { best = bd; q.dx = bdx; q.dy = bdy; q.t0 = b0; q.t1 = b1; q.t2 = b2; q.hint = kHintEdge1; }
+        if (cd < best) { best = cd; q.dx = cdx; q.dy = cdy; q.t0 = c0; q.t1 = c1; q.t2 = c2; q.hint = kHintEdge2; }
         q.sign = 1.f;
         return true;
     }
@@ -846,6 +878,7 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp,
         v0 = m == 2 ? 0 : m + 1;
     }
     const bool e0 = v0 == 0, e1 = v0 == 1;       // selected edge: v0 -> v0+1
+    q.hint = e0 ? kHintEdge0 : (e1 ? kHintEdge1 : kHintEdge2);
     // read every candidate into a value first: selecting between array elements directly lets the compiler
     // turn the select into a dynamically indexed load, which would push the record out of SGPRs
     const float E00 = r[kRecEdge + 0], E01 = r[kRecEdge + 1], E02 = r[kRecEdge + 2];
@@ -871,15 +904,16 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp,
 }
 
 // The same closest-point evaluation for a pair whose edge is already known (backward: the forward kernel recorded, per
-// pair, which edge point_to_face() selected): one edge instead of three candidates resp. the corner logic, the very
-// expressions of the two branches above on the very operands (inside: t, 1 - t unclamped, :99-105; outside: clamped, :150-158).
-__device__ __forceinline__ void point_to_face_edge(Pair& q, const float* r, int e)
+// pair, which edge point_to_face() selected -- the pair hints, see kHintDead): one edge instead of three candidates resp.
+// the corner logic, the very expressions of the two branches above on the very operands (inside: t, 1 - t unclamped,
+// :99-105; outside: clamped, :150-158), so dx, dy, t and with them the fragment are bit for bit the forward kernel's.
+// e0 / e1: the selected edge is 0 / 1 (neither: 2).
+__device__ __forceinline__ void point_to_face_edge(Pair& q, const float* r, bool e0, bool e1)
 {
     const float w0 = q.w0, w1 = q.w1, w2 = q.w2;
     const float x0 = r[kRecXY + 0], y0 = r[kRecXY + 1], x1 = r[kRecXY + 2], y1 = r[kRecXY + 3],
                 x2 = r[kRecXY + 4], y2 = r[kRecXY + 5];
     const bool inside = w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1;
-    const bool e0 = e == 0, e1 = e == 1;
     const float E00 = r[kRecEdge + 0], E01 = r[kRecEdge + 1], E02 = r[kRecEdge + 2];
     const float E10 = r[kRecEdge + 3], E11 = r[kRecEdge + 4], E12 = r[kRecEdge + 5];
     const float E20 = r[kRecEdge + 6], E21 = r[kRecEdge + 7], E22 = r[kRecEdge + 8];
@@ -925,20 +959,18 @@ __device__ __forceinline__ void barycentrics(Pair& q, const float* r, float xp, 
 // stage 2 on r[16..34): soft fragment of a pair whose pixel is inside the box.  Returns true if the pair
 // contributes (none of the skips at :769, :784 fires).
 template <int DIST, int SQ>
-__device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp, float yp, const RenderArgs& a, const DistParams& dp, int edge = -1)
+__device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp, float yp, const RenderArgs& a, const DistParams& dp,
+                                              bool hinted = false, bool e0 = false, bool e1 = false)
 {
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     if (dist == kHeaviside) {
-        q.sign = 0.f; q.dx = 0.f; q.dy = 0.f; q.dis = 0.f; q.t0 = q.t1 = q.t2 = 0.f;
+        q.sign = 0.f; q.dx = 0.f; q.dy = 0.f; q.dis = 0.f; q.t0 = q.t1 = q.t2 = 0.f; q.hint = kHintEdge0;
         q.frag = inside_closed(q) ? 1.f : 0.f;                                      // :762-764
     } else {
-#if GENDR_EXP_KNOWN
-        if (edge >= 0) point_to_face_edge(q, r, edge);
-        else
-#endif
-        if (!point_to_face(q, r, xp, yp)) return false;
+        if (hinted) point_to_face_edge(q, r, e0, e1);
+        else if (!point_to_face(q, r, xp, yp)) return false;
         float dis = q.dx * q.dx + q.dy * q.dy;                                      // :768
-        if (q.sign < 0 && dis >= a.thr) return false;                               // :769
+        if (!hinted && q.sign < 0 && dis >= a.thr) return false;                    // :769 (a hinted pair passed it in the forward kernel)
         const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
         if (!squared) dis = sqrt_rn(dis);                                           // :770-772 (== sqrtf, see sqrt_rn)
         q.dis = dis;
@@ -946,7 +978,7 @@ __device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp,
         else if constexpr (DIST == -2) q.frag = cdf_light_rt(dist, q.sign, dis, dp);
         else                           q.frag = cdf_rt(dist, q.sign, dis, dp);
     }
-    return !((double)q.frag <= kProbThreshold);                                     // :784
+    return hinted || !((double)q.frag <= kProbThreshold);                           // :784
 }
 
 // barycentric_clip + depth, kernel.cu:68-72, :807-810
@@ -1434,11 +1466,15 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 #endif
 
     tw.split_log2 = walk_split_log2(tw, a.resident_q);
+    // pair hints for backward (PairHints): written while no tile of the queue is split among several waves
+    const bool hints_q = a.hints != nullptr && tw.split_log2 == 0;
+    if (hints_q && tw.rank == 0 && (threadIdx.x & 63) == 0) atomicOr(a.control + (blockIdx.x & 7) * kCtlStride + kCtlHintFlag, 1);
     for (; tw.next < (tw.total << tw.split_log2); tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
     const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
+    PairHints* hint_slot = (hints_q && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's slot (a tile without a slice of the entry pool has none)
     TileCtx t;
     tile_setup(t, a, ti.x);
     t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels this wave renders
@@ -1474,6 +1510,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             __hip_atomic_fetch_or(&s_mask[wave][code & 63], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         // ---- phase B: one pair per lane
+        float hint = 0.f;                                       // what backward may know about the pair (PairHints); +0: no gradient
         if (lane < np) {
             const int fn = code >> 6;
             const long face_lin = (long)t.b * a.nf + fn;
@@ -1489,8 +1526,9 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fn = fn; res.pad1 = 0;
             if (kSil) {
                 // alpha needs the fragment only: the reference folds it before it looks at the depth (:795-810)
-                if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) { res.flags = kFlagContrib; res.frag = q.frag; }
+                if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) { res.flags = kFlagContrib; res.frag = q.frag; hint = q.hint; }
             } else if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) {
+                hint = q.hint;                  // (backward repeats the depth test :810 / :994 itself: it needs the depth anyway)
                 gather_record<kGatherB0, REC / 4>(r, rg);
                 res.flags = kFlagContrib;
                 res.frag = q.frag;
@@ -1511,6 +1549,19 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
                 }
             }
             s_res[wave][lane] = res;
+        }
+        if (hint_slot) {
+            // The batch's pair hints for backward: one compare per hint word, and the 16 bytes leave through the SCALAR
+            // data cache (s_store_dwordx4: the ballots are scalar registers already; a vector store by one lane costs four moves,
+            // the address and the exec juggling -- measured +1.3 us per launch at the headline scene).  Written back by the
+            // s_dcache_wb at the end of the wave; partial lines shared with other waves are byte-masked (tools/micro/sstore.hip).
+            typedef unsigned u4s __attribute__((ext_vector_type(4)));
+            const unsigned long long h_lo = __ballot(hint_bit0(hint));
+            const unsigned long long h_hi = __ballot(hint_bit1(hint));
+            u4s hv; hv.x = (unsigned)h_lo; hv.y = (unsigned)(h_lo >> 32); hv.z = (unsigned)h_hi; hv.w = (unsigned)(h_hi >> 32);
+            asm volatile("s_store_dwordx4 %0, %1, 0x0" :: "s"(hv), "s"(hint_slot) : "memory");
+            hint_slot++;
+            if (__ballot(hint_none(hint)) && lane == 0) atomicOr(a.control + (blockIdx.x & 7) * kCtlStride + kCtlHintFlag, 2);
         }
         __builtin_amdgcn_wave_barrier();
 #if GENDR_ABLATE == 2
@@ -1591,6 +1642,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     }
     __builtin_amdgcn_wave_barrier();
     }   // tile loop
+    if (hints_q) asm volatile("s_waitcnt lgkmcnt(0)\n s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");   // the hints' scalar stores reach the L2
     GENDR_SPAN_END(2, blockIdx.x * WAVES + wave);
 }
 
@@ -1641,7 +1693,8 @@ struct PixIn {             // 48 bytes: per-pixel inputs of the backward pass, k
 
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, bool PRELOADED = false>
 __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistParams& dp, const float* rg, const PixIn& px, int fn, long face_lin,
-                                              float (&gv)[9], float (&gt)[GradTex<TEXM>::n], int& tex_own, float (&tex_val)[3])
+                                              float (&gv)[9], float (&gt)[GradTex<TEXM>::n], int& tex_own, float (&tex_val)[3],
+                                              bool hinted = false, bool e0 = false, bool e1 = false)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int NT = GradTex<TEXM>::n;
@@ -1668,11 +1721,7 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
     // the final select back into such a default).
     float C_xy = 0.f, zp = 0.f;
     float wc[3];
-#if GENDR_EXP_KNOWN
-    bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp, PRELOADED ? -1 : (int)((unsigned)(fn + (int)(px.xp * 1024.f)) % 3u));
-#else
-    bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp);
-#endif
+    bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp, hinted, e0, e1);
     if (live) {
         // alpha only, and this face's depth cannot fail the near / far test (see face_setup_kernel): no depth stage
         const bool need_depth = !(kSil && (__float_as_int(r[kRecBits]) & kBitDepthSafe));
@@ -1882,11 +1931,15 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     GENDR_T(0);                                   // 0: wave start-up (queue lengths)
     GENDR_STAMP(1);
     tw.split_log2 = walk_split_log2(tw, a.resident_q);
+    // the forward kernel's pair hints hold for this queue if it rendered the queue unsplit (and met no pair a hint cannot
+    // describe) and this kernel does not split either: batch k of a tile is then the same 64 pairs in both
+    const bool hinted_q = a.hints != nullptr && tw.hint_flag == 1 && tw.split_log2 == 0;
     for (; tw.next < (tw.total << tw.split_log2); tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
     const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
+    const PairHints* hint_slot = (hinted_q && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's hints
     TileCtx t;
     tile_setup(t, a, ti.x);
     t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels whose pairs this wave differentiates
@@ -1921,6 +1974,17 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             sg.fn = fn_l; sg.span = lane | ((above ? __builtin_ctzll(above) + 1 : np - lane) << 8);
             s_seg[wave][__popcll(heads & lt)] = sg;
         }
+        // the forward kernel's hints for the batch's pairs (PairHints): which edge, or nothing to do at all
+        bool e0 = false, e1 = false, dead = false;
+        const bool hinted = hint_slot != nullptr;
+        if (hinted) {
+            const GENDR_CONST_AS unsigned long long* hp = (const GENDR_CONST_AS unsigned long long*)hint_slot;   // scalar load
+            const unsigned long long h_lo = hp[0], h_hi = hp[1];
+            hint_slot++;
+            e0 = __builtin_amdgcn_inverse_ballot_w64(~h_lo & ~h_hi);
+            e1 = __builtin_amdgcn_inverse_ballot_w64(h_lo & ~h_hi);
+            dead = __builtin_amdgcn_inverse_ballot_w64(h_lo & h_hi);
+        }
         if (lane < np) {
             const PixIn px = s_pix[wave][code & 63];
             const int fn = fn_l;
@@ -1929,7 +1993,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             float gt[NT];                      // texture partials
             int tex_own = -1;
             float tex_val[3] = {0.f, 0.f, 0.f};
-            const bool live = backward_pair<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, recs_g + (long)fn * REC, px, fn, face_lin, gv, gt, tex_own, tex_val);
+            bool live = false;
+            if (!dead) live = backward_pair<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, recs_g + (long)fn * REC, px, fn, face_lin, gv, gt, tex_own, tex_val, hinted, e0, e1);
             if constexpr (TEXM == kTexSurfaceN) {
                 if (live && tex_own >= 0) {
 #pragma unroll

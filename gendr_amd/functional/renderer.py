@@ -109,6 +109,7 @@ def make_params(image_size, background_color, dist_func, dist_scale, dist_square
     p.deterministic = 1 if os.environ.get('GENDR_DETERMINISTIC', '0') == '1' else 0
     p.skip_unlisted_aux = 0
     p.pool_entries_max = int(os.environ.get('GENDR_POOL_ENTRIES_MAX', '0'))
+    p.pair_hints = int(os.environ.get('GENDR_PAIR_HINTS', '0'))     # 0 automatic, 1 on, -1 off (include/gendr_hip.h, ABI 6)
     return p
 
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GENDR_ABI_VERSION 5
+#define GENDR_ABI_VERSION 6
 
 enum {
     GENDR_OK              = 0,
@@ -80,6 +80,18 @@ typedef struct gendr_params {
                                       (16 bytes each) inside the workspace: tiles that find the pool exhausted are
                                       rendered exactly all the same by the slower all-faces walk.  gendr_workspace_bytes
                                       honours it. */
+    /* ---- ABI 6 ---- */
+    int   pair_hints;              /* Pair hints: gendr_forward records, two bits per evaluated (pixel, face) pair, which edge
+                                      of the face the closest-point search selected (kernel.cu:76-165) and whether the pair
+                                      passed the skip tests (:769, :784); gendr_backward then evaluates that one edge instead
+                                      of repeating the search -- same float operations for that edge, bit-identical values.
+                                      0 (default): on when the option set's cull radius is at most 16 pixels (with long
+                                      tails the backward call is not bound by its arithmetic and the forward call's extra
+                                      work does not pay: measured at BASELINE config 4); 1: on; -1: off.  The hints live in
+                                      the workspace (16 bytes per coverage-pool entry; gendr_workspace_bytes honours the
+                                      setting) and are tied to the gendr_forward call that filled it: gendr_face_setup
+                                      alone leaves none and gendr_backward then repeats the search. */
+    int   reserved_;
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward

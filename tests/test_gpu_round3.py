@@ -117,3 +117,82 @@ def test_unlisted_aux_is_left_alone_when_asked(native_lib):
     gf1, gt1 = R.native_backward(faces, textures, rgba1, aux1, rec1, g, p1)
     assert float((gf0 - gf1).abs().max()) <= 2e-5 * float(gf0.abs().max())
     assert float((gt0 - gt1).abs().max()) <= 2e-5 * float(gt0.abs().max())
+
+
+HINT_CASES = [(n, o) for n, o in scenes.OPTION_MATRIX if n in (
+    'uniform_prob_softmax', 'uniform_prob_hardrgb', 'hard_hard_hard', 'gauss_sq_einstein', 'logistic_prob', 'gamma_yager_vertex',
+    'uniform_T4', 'uniform_singleside', 'uniform_smalleps', 'laplace_frank')]
+
+
+@pytest.mark.parametrize("name,opts", HINT_CASES, ids=[n for n, _ in HINT_CASES])
+def test_pair_hints_change_nothing_but_speed(oracle_mod, native_lib, name, opts):
+    """gendr_params.pair_hints (ABI 6): with the forward kernel's hints the backward kernel evaluates the ONE edge the
+    closest-point search selected in the forward pass instead of repeating the search -- the same float operations for that
+    edge.  Forward results are untouched; the gradients equal those of the hint-less call up to the order of the float
+    atomics (both calls use them), and pass the element-wise rule against the oracle."""
+    for maker, isz in ((scenes.sphere, 64), (scenes.soup, 48), (scenes.slivers, 48)):
+        fv, tex = _inputs(opts, maker)
+        grad = np.random.RandomState(2).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
+        on = parity.run_hip(fv, tex, isz, dict(opts, pair_hints=1), grad)
+        off = parity.run_hip(fv, tex, isz, dict(opts, pair_hints=-1), grad)
+        assert np.array_equal(on['rgba'], off['rgba'], equal_nan=True) and np.array_equal(on['aggrs_info'], off['aggrs_info'], equal_nan=True)
+        bad, rep, refs = criteria.check_case(fv, tex, isz, opts, on, grad)
+        assert not bad, (name, bad)
+        o32 = refs['o32']
+        for k, ak in (('grad_faces', 'abs_faces'), ('grad_textures', 'abs_textures')):
+            s = parity.stats(on[k], off[k], scale=o32[ak].reshape(on[k].shape))
+            assert s['max_rel'] <= 2e-6, (name, k, s)
+
+
+def test_pair_hints_survive_a_pair_no_hint_can_describe(oracle_mod, native_lib):
+    """A pixel inside a face whose three closest-point candidates all lie 1e4 units away: none of them beats the running
+    minimum 1e8 of kernel.cu:86,112 and the reference leaves dx = dy = t = 0.  No 2-bit hint says that; the forward kernel
+    flags the tile queue instead and backward repeats the whole search there.  Same gradients as without hints, and the
+    oracle's."""
+    fv, tex = scenes.sphere(B=2)
+    fv = fv.copy()
+    fv[:, 0, :, :2] = [[-3e4, -3e4], [3e4, -3e4], [0., 3e4]]       # covers everything, every edge farther than sqrt(1e8)
+    fv[:, 0, :, 2] = 50.0                                           # behind the sphere
+    isz = 64
+    grad = np.random.RandomState(3).randn(2, 4, isz, isz).astype(np.float32)
+    for opts in (dict(), dict(aggr_rgb_func='hard'), dict(dist_func='gaussian', dist_scale=3e-3, dist_squared=True, aggr_alpha_func='einstein')):
+        on = parity.run_hip(fv, tex, isz, dict(opts, pair_hints=1), grad)
+        off = parity.run_hip(fv, tex, isz, dict(opts, pair_hints=-1), grad)
+        assert np.array_equal(on['rgba'], off['rgba'], equal_nan=True)
+        bad, rep, refs = criteria.check_case(fv, tex, isz, opts, on, grad)
+        assert not bad, bad
+        o32 = refs['o32']
+        for k, ak in (('grad_faces', 'abs_faces'), ('grad_textures', 'abs_textures')):
+            s = parity.stats(on[k], off[k], scale=o32[ak].reshape(on[k].shape))
+            assert s['max_rel'] <= 2e-6, (k, s)
+
+
+def test_backward_after_face_setup_alone_takes_no_stale_hints(native_lib):
+    """The hints belong to the gendr_forward call that filled the workspace.  The pybind-shaped backward_render rebuilds the
+    workspace with gendr_face_setup (no forward render): the setup kernel clears the per-queue flag, so backward must not
+    read the hints an EARLIER forward call left in the same memory for a different mesh."""
+    from gendr_amd.functional import renderer as R
+    from gendr_amd import _native
+    L = _native.lib()
+    isz = 64
+    o, extra = parity.split_options(dict(pair_hints=1))
+    p = parity.hip_params(isz, o, extra)
+    fa, ta = scenes.sphere(B=2)
+    fb, tb = scenes.soup(B=2, nf=fa.shape[1])
+    dev = 'cuda:0'
+    A = torch.from_numpy(fa).reshape(2, -1, 9).to(dev).contiguous(); TA = torch.from_numpy(ta).to(dev).contiguous()
+    Bf = torch.from_numpy(fb).reshape(2, -1, 9).to(dev).contiguous(); TB = torch.from_numpy(tb).to(dev).contiguous()
+    g = torch.randn(2, 4, isz, isz, device=dev, generator=torch.Generator(dev).manual_seed(5))
+    rgba_b, aux_b, ws_b = R.native_forward(Bf, TB, p)
+    want_f, want_t = R.native_backward(Bf, TB, rgba_b, aux_b, ws_b, g, p)
+    # a forward call on mesh A leaves ITS hints in a workspace; then only the setup stage runs on mesh B in the same memory
+    rgba_a, aux_a, ws = R.native_forward(A, TA, p)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    e = L.gendr_face_setup(ctypes.c_void_p(Bf.data_ptr()), ctypes.c_void_p(TB.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                           2, Bf.shape[1], 1, ctypes.byref(p), ctypes.c_void_p(st))
+    assert e == 0
+    got_f, got_t = R.native_backward(Bf, TB, rgba_b, aux_b, ws, g, p)
+    scale = float(want_f.abs().max())
+    assert float((got_f - want_f).abs().max()) <= 1e-5 * scale
+    assert float((got_t - want_t).abs().max()) <= 1e-5 * max(1e-30, float(want_t.abs().max()))

@@ -155,21 +155,33 @@ def test_workspace_of_radiusless_option_sets_has_no_pool(native_lib):
     import ctypes
     from gendr_amd.functional import renderer as R
     bg = [0., 0., 0.]
+    hints = 0
 
     def ws(B, nf, isz, **kw):
         o = dict(dist_func='uniform', dist_scale=1e-2, dist_squared=False, dist_shape=None, dist_shift=None, dist_eps=1e4,
                  aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=None, aggr_rgb_func='softmax', aggr_rgb_eps=1e-3,
                  aggr_rgb_gamma=1e-3, near=1, far=100, double_side=False, texture_type='surface')
         limit = kw.pop('pool_entries_max', 0)
+        nonlocal hints
+        saved = hints
+        if kw.pop('pair_hints_off', False):
+            hints = -1
         o.update(kw)
         p = R.make_params(isz, bg, *[o[k] for k in ('dist_func', 'dist_scale', 'dist_squared', 'dist_shape', 'dist_shift', 'dist_eps',
                                                    'aggr_alpha_func', 'aggr_alpha_t_conorm_p', 'aggr_rgb_func', 'aggr_rgb_eps',
                                                    'aggr_rgb_gamma', 'near', 'far', 'double_side', 'texture_type')])
         p.pool_entries_max = limit
+        p.pair_hints = hints
+        hints = saved
         return int(native_lib.gendr_workspace_bytes(B, nf, 1, ctypes.byref(p)))
 
+    hints = -1
     base = ws(64, 1280, 256)
     assert base < 200e6                                         # C2: records + masks + pool
+    hints = 0                                                   # automatic: C2's 1.3-pixel cull radius gets pair hints (ABI 6),
+    with_hints = ws(64, 1280, 256)                              # one 16-byte slot per pool entry
+    assert base < with_hints < 300e6
+    assert ws(256, 1280, 512, dist_func='logistic') == ws(256, 1280, 512, dist_func='logistic', pair_hints_off=True)   # C4 (37 pixels): none
     for dist in ('cauchy', 'reciprocal'):
         assert ws(64, 1280, 256, dist_func=dist) < 40e6         # records, queues, queue records only
         assert ws(256, 1280, 512, dist_func=dist) < 200e6       # C4 size: was 20 GiB
