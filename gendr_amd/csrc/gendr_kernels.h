@@ -978,7 +978,10 @@ __device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp,
         else if constexpr (DIST == -2) q.frag = cdf_light_rt(dist, q.sign, dis, dp);
         else                           q.frag = cdf_rt(dist, q.sign, dis, dp);
     }
-    return hinted || !((double)q.frag <= kProbThreshold);                           // :784
+    // :784 compares the float fragment with the double literal 1e-6.  (float)1e-6 lies BELOW 1e-6, so the floats that are
+    // <= 1e-6 are exactly those <= (float)1e-6: one float compare (NaN: neither form skips the pair)
+    static_assert((double)(float)kProbThreshold <= kProbThreshold, "the float compare needs RN(threshold) <= threshold");
+    return hinted || !(q.frag <= (float)kProbThreshold);                            // :784
 }
 
 // barycentric_clip + depth, kernel.cu:68-72, :807-810
@@ -988,7 +991,9 @@ __device__ __forceinline__ float clip_and_depth(const Pair& q, const float* r, f
     wc[1] = fmaxf(fminf(q.w1, 1.f), 0.f);
     wc[2] = fmaxf(fminf(q.w2, 1.f), 0.f);
     float s = wc[0] + wc[1] + wc[2];
-    s = ((double)s > 1e-5) ? s : (float)1e-5;              // max(sum, 1e-5) with a double literal, stored as float
+    // max(sum, 1e-5) with a double literal, stored as float: (float)1e-5 lies below 1e-5, so s > 1e-5 iff s > (float)1e-5
+    static_assert((double)(float)1e-5 < 1e-5, "the float compare needs RN(1e-5) < 1e-5");
+    s = (s > (float)1e-5) ? s : (float)1e-5;
     const double rs = rcp_for_div_by((double)s);           // three float quotients by one float divisor (s >= 1e-5)
     wc[0] = div_by(wc[0], rs); wc[1] = div_by(wc[1], rs); wc[2] = div_by(wc[2], rs);
     return rcp_rn(div_by(wc[0], rec_double(r, kRecRZ + 0)) + div_by(wc[1], rec_double(r, kRecRZ + 2)) + div_by(wc[2], rec_double(r, kRecRZ + 4)));   // "1. /": one rounding
@@ -1843,7 +1848,7 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
                         }
                     }
 #else
-                    const float rlen = ((double)len >= 1e-6) ? grad_rcp(len) : 1e6f;
+                    const float rlen = (len > (float)1e-6) ? grad_rcp(len) : 1e6f;      // len >= 1e-6 (double) iff len > (float)1e-6 < 1e-6
                     const float sx = q.sign * C_xy * (q.dx * rlen), sy = q.sign * C_xy * (q.dy * rlen);
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
