@@ -87,6 +87,9 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 #define GENDR_T(i) do {} while (0)
 #endif
 
+#ifndef GENDR_BIN_WAVES
+#define GENDR_BIN_WAVES 8     // waves per SIMD the binning kernel is compiled for: 8 = four 8-wave workgroups per CU (its 106 scalar registers allowed three)
+#endif
 #ifndef GENDR_PAIR_HINTS
 #define GENDR_PAIR_HINTS 1   // 0: no pair hints from the forward to the backward kernel (A/B builds)
 #endif
@@ -566,7 +569,7 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int& total)
     return incl - v;
 }
 
-__global__ __launch_bounds__(kBinThreads) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
+__global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BIN_WAVES, GENDR_BIN_WAVES))) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
 {
     __shared__ unsigned long long s_words[64][kBinGroup + 1];
     __shared__ int s_listed[64];
