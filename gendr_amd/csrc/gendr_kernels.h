@@ -1206,29 +1206,43 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 float r[kRecStage1];
                 gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
                 unsigned m8 = 0u;
-                // The entries only have to be a superset of the contributing pairs (every pair still meets the reference's
-                // own skip tests in the render kernels), so the barycentrics of a row are stepped from its first pixel
-                // instead of being evaluated eight times: w += a * pitch.  Against the expression the edge thresholds were
-                // derived for (barycentrics(), three roundings) the stepped value is off by at most a dozen roundings of
-                // magnitudes below |a| + |b| + |c| (|x|, |y| <= 1) -- a worst-case count gives 17 roundings = 1.06 * 2^-20 of that
-                // sum: the thresholds are lowered by 2^-19 of it (about 2e-4 pixel) and a pixel is dropped only below them.
-                // NaN and infinite coefficients drop nothing.
+                // The entries only have to be a SUPERSET of the contributing pairs (every pair still meets the reference's own
+                // skip tests in the render kernels).  Along a pixel row each barycentric is linear in the column c = 0..7,
+                // w_k(c) = w_k(0) + c d_k, so the columns that pass all three edge thresholds and the cull box form ONE interval:
+                // its ends are three quotients (t_k - w_k(0)) / d_k and two box quotients -- about half the vector instructions
+                // of testing the eight pixels one by one (round 2 stepped w_k from pixel to pixel: 30.0 -> 27.2 us at C2; the
+                // interval form: see DESIGN.md).  Error budget, all towards MORE pixels: the thresholds t_k are lowered by
+                // 2^-19 (|a| + |b| + |c|) -- the model w_k(0) + c d_k and the expression the thresholds were derived for
+                // (barycentrics(), three roundings, on the pixel centre pixel_coord() returns) differ by a few roundings of
+                // magnitudes below that sum, as before; the quotients (one rounded subtraction, v_rcp_f32, one product: relative
+                // error < 2^-21, i.e. < 2^-17 columns wherever the bound lies within [-1, 9]) and the pixel pitch model of the box
+                // test (< 2^-13 columns up to 4096^2) are covered by widening the interval by kColSlack = 2^-8 column at either
+                // end.  A coefficient that is zero, tiny, infinite or NaN makes its constraint constant along the row (kept unless
+                // it provably fails); NaN never drops a pixel (v_max / v_min return the other operand).
                 if (has && row_ok && !(yp_a > r[kRecBox + 3] || yp_a < r[kRecBox + 2])) {
                     constexpr float kSlack = 1.9073486328125e-06f;                     // 2^-19
-                    float w0 = r[kRecInv + 0] * xs[0] + r[kRecInv + 1] * yp_a + r[kRecInv + 2];
-                    float w1 = r[kRecInv + 3] * xs[0] + r[kRecInv + 4] * yp_a + r[kRecInv + 5];
-                    float w2 = r[kRecInv + 6] * xs[0] + r[kRecInv + 7] * yp_a + r[kRecInv + 8];
-                    const float t0 = r[kRecWCull + 0] - kSlack * (fabsf(r[kRecInv + 0]) + fabsf(r[kRecInv + 1]) + fabsf(r[kRecInv + 2]));
-                    const float t1 = r[kRecWCull + 1] - kSlack * (fabsf(r[kRecInv + 3]) + fabsf(r[kRecInv + 4]) + fabsf(r[kRecInv + 5]));
-                    const float t2 = r[kRecWCull + 2] - kSlack * (fabsf(r[kRecInv + 6]) + fabsf(r[kRecInv + 7]) + fabsf(r[kRecInv + 8]));
-                    const float d0 = r[kRecInv + 0] * pitch, d1 = r[kRecInv + 3] * pitch, d2 = r[kRecInv + 6] * pitch;
-                    const float xlo = r[kRecBox + 0], xhi = r[kRecBox + 1];
+                    constexpr float kColSlack = 0.00390625f;                           // 2^-8
+                    float lo = -1.f, hi = 9.f;                                         // the interval of columns, in column units
+                    bool none = false;
 #pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const bool live = t.x0 + c < a.is && !(xs[c] > xhi || xs[c] < xlo) && !(w0 < t0 || w1 < t1 || w2 < t2);
-                        m8 |= (live ? 1u : 0u) << c;
-                        w0 += d0; w1 += d1; w2 += d2;
+                    for (int k = 0; k < 3; k++) {
+                        const float ak = r[kRecInv + 3 * k], bk = r[kRecInv + 3 * k + 1], ck = r[kRecInv + 3 * k + 2];
+                        const float w = ak * xs[0] + bk * yp_a + ck;
+                        const float tk = r[kRecWCull + k] - kSlack * (fabsf(ak) + fabsf(bk) + fabsf(ck));
+                        const float dk = ak * pitch;
+                        const float u = tk - w;                                        // the row passes where c dk >= u
+                        const float q = u * __builtin_amdgcn_rcpf(dk);
+                        const bool up = dk > 1e-30f, down = dk < -1e-30f;
+                        lo = fmaxf(lo, up ? q : -1.f);
+                        hi = fminf(hi, down ? q : 9.f);
+                        none = none || (!up && !down && u > 8e-30f);                   // constant along the row (to 7e-30), and failing
                     }
+                    const float half_is = 0.5f * (float)a.is;                          // 1 / pitch
+                    lo = fmaxf(lo, (r[kRecBox + 0] - xs[0]) * half_is);
+                    hi = fminf(hi, (r[kRecBox + 1] - xs[0]) * half_is);
+                    const int c_first = max(0, (int)ceilf(fminf(lo, 16.f) - kColSlack));
+                    const int c_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(hi, -2.f) + kColSlack));
+                    if (!none && c_last >= c_first) m8 = ((2u << c_last) - 1u) & ~((1u << c_first) - 1u);
                 }
                 my_pairs += __popc(m8);
                 const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
