@@ -532,7 +532,7 @@ __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry
 }
 
 #ifndef GENDR_BIN_LOOP_MAX
-#define GENDR_BIN_LOOP_MAX 16
+#define GENDR_BIN_LOOP_MAX 6
 #endif
 #ifndef GENDR_BIN_THREADS
 #define GENDR_BIN_THREADS 512
@@ -631,24 +631,33 @@ __global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GEN
                     if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << l;
                 }
             } else {
-                // many (the super-tiles under the object): the same predicate is separable, so every face lane marks
-                // the tile columns and tile rows its box meets and one ballot per tile collects that tile's word
-                unsigned mx = 0u, my = 0u;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    // column k's x-range is held by lane k (row 0), row k's y-range by lane 8k (column 0)
-                    const float cx_lo = bcast(rx_lo, k), cx_hi = bcast(rx_hi, k), cy_lo = bcast(ry_lo, 8 * k), cy_hi = bcast(ry_hi, 8 * k);
-                    const bool hx = cull ? !(cx_lo > box.y || cx_hi < box.x) : true;
-                    const bool hy = cull ? !(cy_lo > box.w || cy_hi < box.z) : true;
-                    mx |= (hx ? 1u : 0u) << k;
-                    my |= (hy ? 1u : 0u) << k;
+                // many (the super-tiles under the object): the predicate is separable, and the tile columns (rows) a box meets
+                // are one run of the eight.  Every face lane turns its box into the two runs -- in pixel-index space, i =
+                // (x + 1) is / 2 - 1/2, rounded OUTWARDS by 2^-6 pixel (the float error is below 2^-10 pixel up to 4096^2): the
+                // tile masks only have to be a superset, the coverage kernel applies the exact per-pixel box test -- then one
+                // ballot per column and per row (16, not one per tile: 64) and every tile lane picks its column's and its row's
+                // word with lane-constant select masks.  NaN boxes keep every tile, as the comparisons of rect_hits_box() do.
+                unsigned mx = 0xffu, my = 0xffu;
+                if (cull) {
+                    constexpr float kPixSlack = 0.015625f;                             // 2^-6 pixel
+                    const float half_is = 0.5f * (float)is, fis = (float)is;
+                    const float px_lo = (box.x + 1.f) * half_is - 0.5f, px_hi = (box.y + 1.f) * half_is - 0.5f;      // pixel columns of the box
+                    const float pr_lo = fis - 0.5f - (box.w + 1.f) * half_is, pr_hi = fis - 0.5f - (box.z + 1.f) * half_is;   // pixel rows (row 0 = top = largest y)
+                    const float X0 = (float)(sx * 64), Y0 = (float)(sy * 64);
+                    const int kx_lo = (int)fmaxf(ceilf((px_lo - X0 - 7.f - kPixSlack) * 0.125f), 0.f), kx_hi = (int)fminf(floorf((px_hi - X0 + kPixSlack) * 0.125f), 7.f);
+                    const int ky_lo = (int)fmaxf(ceilf((pr_lo - Y0 - 7.f - kPixSlack) * 0.125f), 0.f), ky_hi = (int)fminf(floorf((pr_hi - Y0 + kPixSlack) * 0.125f), 7.f);
+                    mx = kx_hi >= kx_lo && kx_lo <= 7 && kx_hi >= 0 ? ((2u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u) : 0u;
+                    my = ky_hi >= ky_lo && ky_lo <= 7 && ky_hi >= 0 ? ((2u << ky_hi) - 1u) & ~((1u << ky_lo) - 1u) : 0u;
                 }
                 if (!((cand >> lane) & 1ull)) mx = 0u;              // also drops lanes without a face
+                unsigned long long colw = 0ull, roww = 0ull;
 #pragma unroll
-                for (int tl = 0; tl < 64; tl++) {
-                    const unsigned long long word = __ballot(((mx >> (tl & 7)) & 1u) && ((my >> (tl >> 3)) & 1u));
-                    if (lane == tl) mine = word;
+                for (int k = 0; k < 8; k++) {
+                    const unsigned long long cm = __ballot((mx >> k) & 1u), rm = __ballot((my >> k) & 1u);
+                    if (__builtin_amdgcn_inverse_ballot_w64(0x0101010101010101ull << k)) colw = cm;     // lanes of tile column k
+                    if (__builtin_amdgcn_inverse_ballot_w64(0xffull << (8 * k))) roww = rm;             // lanes of tile row k
                 }
+                mine = colw & roww;
             }
             s_words[lane][ci] = mine;
         }
