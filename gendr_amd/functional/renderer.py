@@ -259,6 +259,9 @@ class GenDRFunction(Function):
             ctx.grad_buffers = (flat, gf, gt)
         # aggrs_info stays inside this Function (saved for backward, which never looks at tiles no face reaches)
         params.skip_unlisted_aux = 1 if os.environ.get('GENDR_SKIP_UNLISTED_AUX', '1') != '0' else 0
+        # pair hints (ABI 6) are for the backward call: a forward pass nobody differentiates does not pay for them
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and params.pair_hints == 0:
+            params.pair_hints = -1
         try:
             soft_colors, aggrs_info, records = native_forward(faces, tex, params)
         finally:                               # a failed call must not leave a dangling clear_ptr on the params object

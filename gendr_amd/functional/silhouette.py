@@ -33,6 +33,8 @@ def _forward(face_vertices, params, target=None, want_grad=False):
     faces = face_vertices.detach().reshape(B, nf, 9).to(torch.float32).contiguous()
     dev = faces.device
     grad_faces = None
+    if not want_grad and params.pair_hints == 0:
+        params.pair_hints = -1               # pair hints (ABI 6) serve the backward call only
     if want_grad and B * nf > 0:
         n = (B * nf * 9 + 3) // 4 * 4
         flat = torch.empty(n, dtype=torch.float32, device=dev)
