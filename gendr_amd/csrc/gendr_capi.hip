@@ -656,11 +656,11 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     const long clear_quads = clear4 ? (long)(p->clear_floats / 4) : 0;
     const float cull_r = gendr_cull_radius(p);
     if (texm == kTexSurface1)
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, clear4, clear_quads);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L);
     else if (texm == kTexVertex)
-        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, clear4, clear_quads);
+        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L);
     else
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, clear4, clear_quads);
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L);
     int e = check_launch();
     if (e != GENDR_OK) return e;
     // one workgroup per (image, 64x64 super-tile): tile masks and the tile queues
@@ -668,7 +668,7 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     fill_args(a, workspace, textures, B, nf, T, p);
     const long bblocks = (long)B * w.supers_x * w.supers_x;
     if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
-    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kBinThreads), 0, s, boxes, a, w.supers_x, p->cull);
+    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kBinThreads), 0, s, boxes, a, w.supers_x, p->cull, clear4, clear_quads);   // (also clears the caller's gradient buffer)
     e = check_launch();
     if (e != GENDR_OK) return e;
     // coverage entries of the listed tiles: one wave per queue slot, same walk as the render kernels

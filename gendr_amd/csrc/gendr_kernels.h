@@ -569,8 +569,14 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int& total)
     return incl - v;
 }
 
-__global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BIN_WAVES, GENDR_BIN_WAVES))) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull)
+__global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BIN_WAVES, GENDR_BIN_WAVES))) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull,
+                                                                                                                        float4* __restrict__ clear4, long clear_quads)
 {
+    // the caller's buffer to clear (gendr_params::clear_ptr: the gradients of the coming backward call): one 16-byte store per
+    // thread or so, issued before anything else -- this kernel has 400 times the threads of the per-face setup kernel (which
+    // did it until round 3 and paid 2.6 us for it: its waves run alone on their SIMDs)
+    for (long q = (long)blockIdx.x * kBinThreads + threadIdx.x; q < clear_quads; q += (long)gridDim.x * kBinThreads)
+        clear4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     __shared__ unsigned long long s_words[64][kBinGroup + 1];
     __shared__ int s_listed[64];
     GENDR_SPAN_BEGIN;
