@@ -383,14 +383,15 @@ def measure(args, wl, dist, dev):
                 launch = 'eager'
         fence()
         # Kernel durations come from HIP events around the native calls, recorded live inside the timed region -- but
-        # only on a sample of the steps (two of them: the first and the middle one): a timed event drains the queue around it
-        # (about 10 us each on this stack; four per step cost 11 % of the throughput when every step carried them).
+        # only on TWO of the steps, the first and the last: a timed event serialises the launches around it (about 10 us each on
+        # this stack; four per step cost 11 % of the throughput when every step carried them), and in the middle of the loop it
+        # also lets the queue run dry, which the host -- only ~15 us per step faster than the GPU at C2 -- takes steps to refill.
         # Sampled steps are always launched eagerly (an event cannot be recorded inside a replayed graph).
         events, coll = [], []
-        stride = max(1, (args.steps + 1) // 2)
+        sampled = {0, args.steps - 1}
         t0 = time.perf_counter()
         for i in range(args.steps):
-            if i % stride == 0 and wl.B > 0:
+            if i in sampled and wl.B > 0:
                 e = [torch.cuda.Event(enable_timing=True) if (k >= 2 or not events) else None for k in range(4)]
                 if wl.cfg.get('gather'):
                     gdist.PROFILE_EVENTS = c = []

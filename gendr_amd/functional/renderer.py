@@ -121,8 +121,34 @@ def check(code, what):
         raise RuntimeError(msg)
 
 
-def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _stream_ptr(device=None):
+    """The caller's current HIP stream on `device` (default: the current device) as a void*.  The raw-stream query is a
+    plain C call; building a torch.cuda.Stream object for it costs ten times as much, and the eager step of the headline
+    bench is only a few tens of microseconds of host work away from being host-bound."""
+    if _raw_stream is not None:
+        idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+        return ctypes.c_void_p(_raw_stream(idx))
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when `dev` is not the current device already (the context manager costs ~10 us)."""
+    __slots__ = ('ctx',)
+
+    def __init__(self, dev):
+        self.ctx = None if (dev.index is None or dev.index == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 def _ptr(t):
@@ -152,7 +178,7 @@ def native_forward(faces, textures, params, rgba=None, aggrs_info=None):
     nbytes = (L.gendr_workspace_bytes_f64 if f64 else L.gendr_workspace_bytes)(B, nf, T, ctypes.byref(params))
     records = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
     ev = PROFILE_EVENTS
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         if ev is not None and ev[0] is not None:
             ev[0].record()
         check((L.gendr_forward_f64 if f64 else L.gendr_forward)(
@@ -188,7 +214,7 @@ def native_backward(faces, textures, rgba, aggrs_info, records, grad_rgba, param
     if grad_textures is None:
         grad_textures = torch.zeros(textures.shape, dtype=dt, device=dev)
     ev = PROFILE_EVENTS
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         if ev is not None:
             ev[2].record()
         check((L.gendr_backward_f64 if f64 else L.gendr_backward)(

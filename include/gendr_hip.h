@@ -61,8 +61,8 @@ typedef struct gendr_params {
     int   texel_mode;              /* 0: reference-faithful surface texel index (kernel.cu:179-184 may
                                          index the following face's texels); 1: clamp to the face's own block */
     int   cull;                    /* 1: exact tile culling (default), 0: visit every (pixel, face) pair */
-    void* clear_ptr;               /* optional, gendr_forward / gendr_face_setup only: a float buffer the per-face setup */
-    unsigned long long clear_floats;   /* kernel zero-fills on the way (16-byte aligned, a multiple of 4 floats) -- the
+    void* clear_ptr;               /* optional, gendr_forward / gendr_face_setup only: a float buffer the setup stage (its   */
+    unsigned long long clear_floats;   /* binning kernel) zero-fills on the way (16-byte aligned, a multiple of 4 floats) -- the
                                       gradient buffers of the coming gendr_backward call, which saves that call's
                                       caller a fill launch.  NULL / 0: nothing is cleared.  Honoured by the float32
                                       entry points (gendr_forward, gendr_silhouette_forward, gendr_face_setup) only. */
