@@ -381,7 +381,6 @@ def measure(args, wl, dist, dev):
                 sys.stderr.write('bench: graph capture failed (%s); eager launches\n' % (e,))
                 graph = None
                 launch = 'eager'
-        fence()
         # Kernel durations come from HIP events around the native calls, recorded live inside the timed region -- but
         # only on TWO of the steps, the first and the last: a timed event serialises the launches around it (about 10 us each on
         # this stack; four per step cost 11 % of the throughput when every step carried them), and in the middle of the loop it
@@ -389,10 +388,13 @@ def measure(args, wl, dist, dev):
         # Sampled steps are always launched eagerly (an event cannot be recorded inside a replayed graph).
         events, coll = [], []
         sampled = {0, args.steps - 1}
+        # (the event objects exist before the clock starts: creating one costs the host ~10 us)
+        ready = {i: [torch.cuda.Event(enable_timing=True) if (k >= 2 or i == 0) else None for k in range(4)] for i in sampled}
+        fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
             if i in sampled and wl.B > 0:
-                e = [torch.cuda.Event(enable_timing=True) if (k >= 2 or not events) else None for k in range(4)]
+                e = ready[i]
                 if wl.cfg.get('gather'):
                     gdist.PROFILE_EVENTS = c = []
                 wl.step(e)

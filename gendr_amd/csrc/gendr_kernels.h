@@ -1977,6 +1977,16 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
     const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
     const PairHints* hint_slot = (hinted_q && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's hints
+    if (hint_slot && ti.w <= 4 * 64) {
+        // a tile whose few batches hold no pair with a gradient is done before its pixel inputs are fetched (an image with a
+        // face seen edge-on lists that face -- no error bound, 64 dead pairs -- in every one of its tiles)
+        unsigned long long all_dead = ~0ull;
+        for (int k = 0; k < ((ti.w + 63) >> 6); k++) {
+            const GENDR_CONST_AS unsigned long long* hp = (const GENDR_CONST_AS unsigned long long*)(hint_slot + k);
+            all_dead &= hp[0] & hp[1];
+        }
+        if (all_dead == ~0ull) continue;
+    }
     TileCtx t;
     tile_setup(t, a, ti.x);
     t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels whose pairs this wave differentiates
@@ -1997,6 +2007,20 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 #if GENDR_ABLATE == 3
         return;
 #endif
+        // the forward kernel's hints for the batch's pairs (PairHints): which edge, or nothing to do at all
+        bool e0 = false, e1 = false, dead = false;
+        const bool hinted = hint_slot != nullptr;
+        if (hinted) {
+            const GENDR_CONST_AS unsigned long long* hp = (const GENDR_CONST_AS unsigned long long*)hint_slot;   // scalar load
+            const unsigned long long h_lo = hp[0], h_hi = hp[1];
+            hint_slot++;
+            // no pair of the batch gets a gradient (lanes past the batch's end read as dead too): nothing to do -- the tiles a
+            // face without an error bound is listed in (seen edge-on: every tile of its image) consist of such batches
+            if ((h_lo & h_hi) == ~0ull) return;
+            e0 = __builtin_amdgcn_inverse_ballot_w64(~h_lo & ~h_hi);
+            e1 = __builtin_amdgcn_inverse_ballot_w64(h_lo & ~h_hi);
+            dead = __builtin_amdgcn_inverse_ballot_w64(h_lo & h_hi);
+        }
         // The batch's codes, and its faces: the pairs of one face are consecutive, so a lane whose face differs from
         // its left neighbour's heads a segment; the ballot of the heads gives every head its slot, first pair and
         // length (a dozen vector instructions per batch for what the entry-by-entry batch builder used to keep).
@@ -2010,17 +2034,6 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             FaceSeg sg;
             sg.fn = fn_l; sg.span = lane | ((above ? __builtin_ctzll(above) + 1 : np - lane) << 8);
             s_seg[wave][__popcll(heads & lt)] = sg;
-        }
-        // the forward kernel's hints for the batch's pairs (PairHints): which edge, or nothing to do at all
-        bool e0 = false, e1 = false, dead = false;
-        const bool hinted = hint_slot != nullptr;
-        if (hinted) {
-            const GENDR_CONST_AS unsigned long long* hp = (const GENDR_CONST_AS unsigned long long*)hint_slot;   // scalar load
-            const unsigned long long h_lo = hp[0], h_hi = hp[1];
-            hint_slot++;
-            e0 = __builtin_amdgcn_inverse_ballot_w64(~h_lo & ~h_hi);
-            e1 = __builtin_amdgcn_inverse_ballot_w64(h_lo & ~h_hi);
-            dead = __builtin_amdgcn_inverse_ballot_w64(h_lo & h_hi);
         }
         if (lane < np) {
             const PixIn px = s_pix[wave][code & 63];
