@@ -43,7 +43,7 @@ class GendrParams(ctypes.Structure):
         ("skip_unlisted_aux", ctypes.c_int),
         ("pool_entries_max", ctypes.c_ulonglong),
         ("pair_hints", ctypes.c_int),
-        ("reserved_", ctypes.c_int),
+        ("loose_faces", ctypes.c_int),
     ]
 
 

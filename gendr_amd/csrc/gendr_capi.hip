@@ -5,6 +5,7 @@
 // stream (the reference uses the null stream, kernel.cu:1103,1118,1190), invalid options are rejected
 // with an error code instead of a device printf + NaN, nothing is allocated here.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <string.h>
 #include <stdio.h>
@@ -120,7 +121,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" float gendr_cull_radius(const gendr_params* p);
 
 struct Workspace {
-    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, hints_off, sorted_off, control_off, det_off, total;
+    size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, hints_off, sorted_off, loose_off, control_off, det_off, total;
     bool ordered;              // the render kernels walk the heavy-first copy of the queue records (order_tiles_kernel)
     bool hints;                // the forward kernel leaves pair hints for the backward kernel (gendr_params::pair_hints)
     int tiles_x, chunks, supers_x, ncontrol;
@@ -194,7 +195,9 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     // where every tile could start at once, made batch 8 slower -- 123 vs 108 us per step -- since the sub-tile split puts
     // more work items than wave slots into the launch); no pool: no pair counts to order by
     w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16 && w.ent_cap8 > 0;
-    w.control_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
+    // faces with a loose cull box (loose_faces_kernel): [flag B*nf i32][box B*nf 4 x i32][list per image B x 16 i32]
+    w.loose_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
+    w.control_off = w.loose_off + align256((size_t)B * nf * sizeof(int)) + align256((size_t)B * nf * sizeof(int4)) + align256((size_t)B * kLooseList * sizeof(int));
     w.ncontrol = kCtlInts;
     // deterministic backward: [count + list of the deferred faces][their band sums]
     w.det_off = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
@@ -244,6 +247,15 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.tile_info = w.ordered ? reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.sorted_off) : a.tile_info_raw;
     a.entries = reinterpret_cast<CoverEnt*>(static_cast<char*>(const_cast<void*>(workspace)) + w.entries_off);
     a.ent_cap8 = w.ent_cap8;
+    {
+        char* lb = static_cast<char*>(const_cast<void*>(workspace)) + w.loose_off;
+        a.loose_flag = reinterpret_cast<const int*>(lb);
+        a.loose_box = reinterpret_cast<int4*>(lb + align256((size_t)B * nf * sizeof(int)));
+        a.loose_image = reinterpret_cast<int*>(lb + align256((size_t)B * nf * sizeof(int)) + align256((size_t)B * nf * sizeof(int4)));
+        const float r = gendr_cull_radius(p);
+        // (radius (1 + 2^-10))^2 rounded up: a computed squared distance that reaches it lies beyond the radius
+        a.cull_r2 = r < 1e18f ? nextafterf((float)((double)r * (double)r * (1. + 1. / 512.)), INFINITY) : INFINITY;
+    }
     a.hints = w.hints ? reinterpret_cast<PairHints*>(static_cast<char*>(const_cast<void*>(workspace)) + w.hints_off) : nullptr;
     a.textures = textures;
     a.B = B; a.nf = nf; a.T = T;
@@ -655,17 +667,38 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     float4* clear4 = p->clear_ptr && total > 0 ? static_cast<float4*>(p->clear_ptr) : nullptr;
     const long clear_quads = clear4 ? (long)(p->clear_floats / 4) : 0;
     const float cull_r = gendr_cull_radius(p);
-    if (texm == kTexSurface1)
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L);
-    else if (texm == kTexVertex)
-        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L);
-    else
-        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L);
-    int e = check_launch();
-    if (e != GENDR_OK) return e;
-    // one workgroup per (image, 64x64 super-tile): tile masks and the tile queues
     RenderArgs a;
     fill_args(a, workspace, textures, B, nf, T, p);
+    // faces with a loose cull box (face_setup_kernel flags them, loose_faces_kernel finds their live pixels): only with a finite
+    // cull radius.  The per-image marks carry a stamp of this call, so that nothing has to be cleared beforehand (whatever the
+    // workspace held: a chance match only makes a workgroup look at its image's flags, which this call did write).
+    static std::atomic<int> stamp_counter{1};
+    // ... and only for images of at least GENDR_LOOSE_MIN_TILES tiles (1024^2): the extra launch costs 10 us when an image has
+    // such a face and 3 us when none has, which at 256^2 is what it saves (C2: forward -5, backward -3, coverage -3 us against
+    // +10; a small batch pays without gaining), while at 2048^2 one such face is listed in 65 536 tiles (C5: +8 %).
+    const bool loose_on = GENDR_LOOSE_FACES && cull_r < INFINITY && total > 0 && p->cull && p->loose_faces >= 0 &&
+                          (p->loose_faces > 0 || (long)a.tiles_per_image >= GENDR_LOOSE_MIN_TILES);
+    if (!loose_on) a.loose_flag = nullptr;
+    a.loose_stamp = (stamp_counter.fetch_add(1) & 0x03ffffff) | 0x04000000;      // 27 bits: the list heads hold stamp << 4 | entries
+    if (texm == kTexSurface1)
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L,
+                           const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
+    else if (texm == kTexVertex)
+        hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L,
+                           const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
+    else
+        hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L,
+                           const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
+    int e = check_launch();
+    if (e != GENDR_OK) return e;
+    if (loose_on) {
+        if (texm == kTexSurface1)    hipLaunchKernelGGL(loose_faces_kernel<record_floats(kTexSurface1)>, dim3(kLooseWaves), dim3(kThreads), 0, s, a);
+        else if (texm == kTexVertex) hipLaunchKernelGGL(loose_faces_kernel<record_floats(kTexVertex)>, dim3(kLooseWaves), dim3(kThreads), 0, s, a);
+        else                         hipLaunchKernelGGL(loose_faces_kernel<record_floats(kTexSurfaceN)>, dim3(kLooseWaves), dim3(kThreads), 0, s, a);
+        e = check_launch();
+        if (e != GENDR_OK) return e;
+    }
+    // one workgroup per (image, 64x64 super-tile): tile masks and the tile queues
     const long bblocks = (long)B * w.supers_x * w.supers_x;
     if (bblocks > 0x7fffffffL) return GENDR_E_SHAPE;
     hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)bblocks), dim3(kBinThreads), 0, s, boxes, a, w.supers_x, p->cull, clear4, clear_quads);   // (also clears the caller's gradient buffer)

@@ -90,6 +90,15 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 #ifndef GENDR_BIN_WAVES
 #define GENDR_BIN_WAVES 8     // waves per SIMD the binning kernel is compiled for: 8 = four 8-wave workgroups per CU (its 106 scalar registers allowed three)
 #endif
+#ifndef GENDR_LOOSE_AREA
+#define GENDR_LOOSE_AREA 1.0f    // visible NDC area of a cull box from which face_setup_kernel calls it loose (the image has 4)
+#endif
+#ifndef GENDR_LOOSE_MIN_TILES
+#define GENDR_LOOSE_MIN_TILES 16384
+#endif
+#ifndef GENDR_LOOSE_FACES
+#define GENDR_LOOSE_FACES 1    // 0: faces without a usable error bound keep the reference's cull box (A/B builds)
+#endif
 #ifndef GENDR_PAIR_HINTS
 #define GENDR_PAIR_HINTS 1   // 0: no pair hints from the forward to the backward kernel (A/B builds)
 #endif
@@ -164,6 +173,9 @@ constexpr int kRecRDen  = 30;   // 3 doubles: 1 / Dn[k],  Dn[k] = A[k][k] - A[k]
 constexpr int kRecXY    = 36;   // x0 y0 x1 y1 x2 y2
 constexpr int kRecRZ    = 42;   // 3 doubles: 1 / z_k   (:809, :1027-1029)
 constexpr int kRecTex   = 48;   // TEXM 0: own rgb, next-face rgb ; TEXM 1: 3 vertex colours ; TEXM 2: nothing
+constexpr int kLooseList = 16;         // ints per image in RenderArgs::loose_image: stamped counter + up to 15 flagged faces
+constexpr int kLooseWaves = 2048;      // grid of loose_faces_kernel (one-wave workgroups)
+constexpr int kRecLoose = 17;  // int bits: 1 = the cull box is loose (no usable error bound); bin / cover kernels then take the box of loose_faces_kernel
 constexpr int kRecStage1 = 20, kRecStage3 = 42;
 constexpr int kBitFront = 8;      // record flag bits next to the obtuse-corner bits 1, 2, 4
 constexpr int kBitDepthSafe = 16; // all three vertex depths well inside [near, far]: the clipped depth cannot fail :810 / :994
@@ -254,6 +266,13 @@ struct RenderArgs {
     int*   det_list;
     float* det_partial;
     int resident_q;             // waves of the launched render kernel the chip holds at once, per tile queue (sub-tile split)
+    // faces whose cull box is loose (see loose_faces_kernel): per face a flag and the box of its live pixels (columns
+    // lo / hi, rows lo / hi; empty: lo > hi), per image a stamp (== loose_stamp: the image has such faces in THIS call)
+    const int*  loose_flag;
+    int4*       loose_box;
+    int*        loose_image;
+    int         loose_stamp;
+    float       cull_r2;        // (cull radius)^2, rounded up: an outside pixel whose computed squared distance reaches it is dead
     gendr_params p;
     float thr;                  // dist_eps * dist_scale (kernel.cu:725)
     float softmax_sum0;         // exp(aggr_rgb_eps / aggr_rgb_gamma) (kernel.cu:729)
@@ -341,7 +360,8 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const float* __restrict__ faces, const float* __restrict__ textures,
     float* __restrict__ boxes, float* __restrict__ records,
     long total_faces, float sthr, float cull_r, int* __restrict__ control, int ncontrol, float near_, float far_,
-    float4* __restrict__ clear4, long clear_quads)
+    float4* __restrict__ clear4, long clear_quads,
+    int* __restrict__ loose_flag, int4* __restrict__ loose_box, int* __restrict__ loose_image, int loose_stamp, int nf)
 {
     constexpr int REC = record_floats(TEXM);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // launched with one wavefront per workgroup
@@ -431,6 +451,37 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         }
     }
 
+    // A LOOSE cull box: the error bound E dwarfs the cull radius (determinant clamped or tiny: the face is seen edge-on), so
+    // the box is the reference's own margin or close to it -- the whole image at the default dist_eps -- and the face would be
+    // listed, with every pixel, in every tile of its image, although next to none of those pairs passes the skip tests.
+    // Such faces (rare; three of the 64 benchmark views hold two each) are flagged here, loose_faces_kernel then evaluates
+    // them on every pixel of their image ONCE, with the render kernels' own pair functions, and leaves the bounding box of the
+    // pixels that can contribute at all; the binning and coverage kernels use that box for them.
+    bool loose = false;
+    if (in_range && cull_r < INFINITY && loose_flag) {
+        const float bw = fminf(xhi, 1.f) - fmaxf(xlo, -1.f), bh = fminf(yhi, 1.f) - fmaxf(ylo, -1.f);         // visible part of the box
+        const float fw = fmaxf(fminf(xmax, 1.f) - fmaxf(xmin, -1.f), 0.f) + 4.f * cull_r, fh = fmaxf(fminf(ymax, 1.f) - fmaxf(ymin, -1.f), 0.f) + 4.f * cull_r;
+        loose = bw > 0.f && bh > 0.f && bw * bh >= GENDR_LOOSE_AREA && bw * bh > 4.f * fw * fh;     // a good part of the image (NDC area 4), four times what the face itself explains
+        loose_flag[i] = loose ? 1 : 0;
+        if (loose) {
+            // append to the image's list: [0] = (this call's stamp << 4 | entries), [1 ..] the faces.  The stamp makes a
+            // counter of its own call out of whatever the word held (nothing is cleared beforehand); a full list leaves
+            // the face its whole image (the state before round 3).
+            int* list = loose_image + (i / nf) * kLooseList;
+            int slot = -1;
+            for (int cur = __hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);;) {
+                const int have = (cur >> 4) == loose_stamp ? (cur & 15) : 0;
+                if (have >= kLooseList - 1) break;
+                const int want = (loose_stamp << 4) | (have + 1);
+                const int seen = atomicCAS(list, cur, want);
+                if (seen == cur) { slot = have; break; }
+                cur = seen;
+            }
+            if (slot >= 0) { list[1 + slot] = (int)(i % nf); loose_box[i] = make_int4(0x7fffffff, -1, 0x7fffffff, -1); }
+            else           loose_box[i] = make_int4(0, 0x7ffffff0, 0, 0x7ffffff0);       // every pixel
+        }
+    }
+
     // bin record: box, then (a, b, c, wcull) per edge.  The edge test is only handed over when the three coefficients are
     // finite (a tile-corner evaluation of an infinite coefficient times a zero pixel coordinate would not bound the
     // per-pixel value, which is NaN there and never rejected).
@@ -459,6 +510,7 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const int depth_safe = (zlo > 0.f && zlo >= near_ * 1.0001f && zhi <= far_ * 0.9999f) ? kBitDepthSafe : 0;
     r[kRecBits] = __int_as_float(g.obt | (g.front << 3) | depth_safe);
     r[kRecWCull + 0] = wcull[0]; r[kRecWCull + 1] = wcull[1]; r[kRecWCull + 2] = wcull[2];
+    r[kRecLoose] = __int_as_float(loose ? 1 : 0);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int k1 = (k + 1) % 3;
@@ -529,6 +581,14 @@ __device__ __forceinline__ float pixel_coord(int idx, int is, double r_is)
 __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry_lo, float ry_hi, const float4& box)
 {
     return !(rx_lo > box.y || rx_hi < box.x || ry_lo > box.w || ry_hi < box.z);
+}
+
+// the cull box of a flagged face from the pixel box loose_faces_kernel left: pixel centres, inclusive (empty: misses everything)
+__device__ __forceinline__ float4 loose_box_ndc(const int4& bx, int is, double r_is)
+{
+    if (bx.x > bx.y || bx.z > bx.w) return make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    if (bx.y >= is || bx.w >= is) return make_float4(-INFINITY, INFINITY, -INFINITY, INFINITY);      // every pixel (a full list, see face_setup_kernel)
+    return make_float4(pixel_coord(bx.x, is, r_is), pixel_coord(bx.y, is, r_is), pixel_coord(is - 1 - bx.w, is, r_is), pixel_coord(is - 1 - bx.z, is, r_is));
 }
 
 #ifndef GENDR_BIN_LOOP_MAX
@@ -624,6 +684,7 @@ __global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GEN
             const bool have = fi < a.nf;
             float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
             if (have) box = (reinterpret_cast<const float4*>(boxes) + ((long)b * a.nf + fi) * (kBinRec / 4))[0];
+            if (have && a.loose_flag && a.loose_flag[(long)b * a.nf + fi]) box = loose_box_ndc(a.loose_box[(long)b * a.nf + fi], is, a.r_is);
             unsigned long long mine = 0ull;
             // Box test only (measured in round 2: an exact per-(face, tile) edge test removes a third of the listings but
             // costs this kernel 43 us at C2; the coverage kernel drops those faces for 10 us).
@@ -1139,6 +1200,93 @@ __device__ __forceinline__ unsigned long long collect_pairs(const TileCtx& t, Re
 }
 
 // ---------------------------------------------------------------------------------------------
+// faces with a loose cull box (face_setup_kernel): the bounding box of the pixels that can contribute
+// ---------------------------------------------------------------------------------------------
+// A fixed grid of one-wave workgroups.  The face_setup kernel left, per image, a short list of its flagged faces behind a
+// stamp of this call (loose_image, kLooseList ints per image).  Every wave looks at the lists of all images (lane = image)
+// and, for the few images that have one, takes every kLooseWaves-th block of 64 consecutive pixels for every listed face:
+// lane = pixel, the face's record arrives by scalar loads, and the pixel is LIVE if it passes the record's (loose) box and is
+// inside the face or the closest-point search of the render kernels -- barycentrics() and point_to_face(), the same float
+// operations on the same operands -- puts it closer than the cull radius (beyond it the pair fails :769 or :784, which is
+// what the radius is defined by; NaN barycentrics drop the pair as everywhere).  Live pixels widen the face's loose_box by
+// integer atomics.  The binning and coverage kernels read that box instead of the record's for a flagged face; everything
+// downstream still applies the reference's own tests to every pair, so the box only has to contain the pixels that can
+// contribute -- it contains exactly the live ones.
+
+template <int REC>
+__global__ __launch_bounds__(kThreads) void loose_faces_kernel(const RenderArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const long P = (long)a.is * a.is;
+    const int nblk = (int)((P + 63) >> 6);
+    constexpr int G = kLooseWaves;                // the grid (a power of two)
+    const int w = (int)blockIdx.x;
+    // Pixel blocks per task (the record is loaded once per task): as few as give every wave of the grid about one task -- the
+    // waves run almost alone on their SIMDs, so the kernel lasts as long as its chain of dependent loads and one task.  Up to 64
+    // images the lists stay in registers (lane = image: the head and the first four faces in one 16-byte load).
+    int flagged = 0;
+    int4 mine = make_int4(0, 0, 0, 0);
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+        const int4 row = b0 + lane < a.B ? *reinterpret_cast<const int4*>(a.loose_image + (long)(b0 + lane) * kLooseList) : make_int4(0, 0, 0, 0);
+        if (b0 == 0) mine = row;
+        int n = (row.x >> 4) == a.loose_stamp ? (row.x & 15) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+        flagged += __builtin_amdgcn_readfirstlane(n);
+    }
+    if (flagged == 0) return;
+    const int kChunk = (int)min(16L, max(1L, ((long)flagged * nblk + G - 1) / G));
+    const int nchunks = (nblk + kChunk - 1) / kChunk;
+    int base = 0;                                 // tasks of the flagged images before this one (mod G): task = (image, face, chunk), wave w takes tasks w, w + G, ...
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+        const int4 row = b0 == 0 ? mine : (b0 + lane < a.B ? *reinterpret_cast<const int4*>(a.loose_image + (long)(b0 + lane) * kLooseList) : make_int4(0, 0, 0, 0));
+        unsigned long long todo = __ballot((row.x >> 4) == a.loose_stamp && (row.x & 15) != 0);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int b = b0 + l;
+            const int n = __builtin_amdgcn_readlane(row.x, l) & 15;
+            const int f1 = __builtin_amdgcn_readlane(row.y, l), f2 = __builtin_amdgcn_readlane(row.z, l), f3 = __builtin_amdgcn_readlane(row.w, l);
+            const int tasks = n * nchunks;                           // (< 2^31: at most 15 faces of at most 2^24 pixel blocks)
+            const RecPtr recs = (RecPtr)a.records + (long)b * a.nf * REC;
+            for (int t = (w - base) & (G - 1); t < tasks; t += G) {
+                const int k = (int)((unsigned)t / (unsigned)nchunks), ch = t - k * nchunks;
+                const int f = k == 0 ? f1 : (k == 1 ? f2 : (k == 2 ? f3 : __builtin_amdgcn_readfirstlane(a.loose_image[(long)b * kLooseList + 1 + k])));
+                float r[kRecStage3];
+                load_record<0, kRecStage3>(r, recs + (long)f * REC);
+                int c_lo = 0x7fffffff, c_hi = -1, r_lo = 0x7fffffff, r_hi = -1;
+                const int blk_end = min(nblk, (ch + 1) * kChunk);
+                for (int blk = ch * kChunk; blk < blk_end; blk++) {
+                    const unsigned p = (unsigned)blk * 64u + (unsigned)lane;         // (P < 2^31: image sizes are validated)
+                    const int row_p = (int)(p / (unsigned)a.is), col = (int)(p - (unsigned)row_p * (unsigned)a.is);
+                    const float xp = pixel_coord(col, a.is, a.r_is), yp = pixel_coord(a.is - 1 - row_p, a.is, a.r_is);
+                    Pair q;
+                    barycentrics(q, r, xp, yp);
+                    bool live = false;
+                    if ((long)p < P && inside_box(r, xp, yp)) {  // (the record's box: the reference's own border test :747 lies inside it)
+                        live = inside_closed(q);                   // (closed: what the heaviside branch of soft_fragment tests)
+                        if (!live && point_to_face(q, r, xp, yp)) live = q.sign > 0.f || q.dx * q.dx + q.dy * q.dy < a.cull_r2;
+                    }
+                    if (live) { c_lo = min(c_lo, col); c_hi = max(c_hi, col); r_lo = min(r_lo, row_p); r_hi = max(r_hi, row_p); }
+                }
+                if (__any(c_hi >= 0)) {
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        c_lo = min(c_lo, __shfl_xor(c_lo, d)); c_hi = max(c_hi, __shfl_xor(c_hi, d));
+                        r_lo = min(r_lo, __shfl_xor(r_lo, d)); r_hi = max(r_hi, __shfl_xor(r_hi, d));
+                    }
+                    if (lane == 0) {
+                        int* bx = reinterpret_cast<int*>(a.loose_box + ((long)b * a.nf + f));
+                        atomicMin(bx + 0, c_lo); atomicMax(bx + 1, c_hi); atomicMin(bx + 2, r_lo); atomicMax(bx + 3, r_hi);
+                    }
+                }
+            }
+            base = (base + tasks) & (G - 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // coverage: which pixels of the tile does each listed face reach?  (once per forward call, shared by both passes)
 // ---------------------------------------------------------------------------------------------
 // One wavefront per listed tile (the same queue walk as the render kernels).  The tile's mask row is first unpacked
@@ -1220,6 +1368,10 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 const int fn = s_flist[has ? i0 + slot : i0];
                 float r[kRecStage1];
                 gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
+                if (has && __float_as_int(r[kRecLoose]) != 0) {             // a loose cull box: the one loose_faces_kernel found instead
+                    const float4 lb = loose_box_ndc(a.loose_box[(long)t.b * a.nf + fn], a.is, a.r_is);
+                    r[kRecBox + 0] = lb.x; r[kRecBox + 1] = lb.y; r[kRecBox + 2] = lb.z; r[kRecBox + 3] = lb.w;
+                }
                 unsigned m8 = 0u;
                 // The entries only have to be a SUPERSET of the contributing pairs (every pair still meets the reference's own
                 // skip tests in the render kernels).  Along a pixel row each barycentric is linear in the column c = 0..7,

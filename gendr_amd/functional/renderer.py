@@ -110,6 +110,7 @@ def make_params(image_size, background_color, dist_func, dist_scale, dist_square
     p.skip_unlisted_aux = 0
     p.pool_entries_max = int(os.environ.get('GENDR_POOL_ENTRIES_MAX', '0'))
     p.pair_hints = int(os.environ.get('GENDR_PAIR_HINTS', '0'))     # 0 automatic, 1 on, -1 off (include/gendr_hip.h, ABI 6)
+    p.loose_faces = int(os.environ.get('GENDR_LOOSE_FACES', '0'))   # likewise
     return p
 
 

@@ -196,3 +196,28 @@ def test_backward_after_face_setup_alone_takes_no_stale_hints(native_lib):
     scale = float(want_f.abs().max())
     assert float((got_f - want_f).abs().max()) <= 1e-5 * scale
     assert float((got_t - want_t).abs().max()) <= 1e-5 * max(1e-30, float(want_t.abs().max()))
+
+
+LOOSE_CASES = [(n, o) for n, o in scenes.OPTION_MATRIX if n in (
+    'uniform_prob_softmax', 'uniform_prob_hardrgb', 'hard_hard_hard', 'gauss_sq_einstein', 'logistic_prob', 'uniform_smalleps',
+    'uniform_singleside', 'gamma_yager_vertex')]
+
+
+@pytest.mark.parametrize("name,opts", LOOSE_CASES, ids=[n for n, _ in LOOSE_CASES])
+def test_loose_face_boxes_change_nothing(native_lib, name, opts):
+    """gendr_params.loose_faces (ABI 6): a face whose cull box is loose (error bound >> cull radius: the sliver and soup scenes are
+    full of them) is evaluated once on every pixel of its image and binned by the bounding box of the pixels that can contribute
+    at all -- instead of being listed in every tile its loose box meets.  Forced on at these small sizes (automatic from 1024^2):
+    forward results bit-identical to the call without it AND to the all-pairs traversal; gradients equal up to atomics order."""
+    for maker, isz in ((scenes.slivers, 64), (scenes.soup, 48), (scenes.sphere, 64)):
+        fv, tex = _inputs(opts, maker)
+        grad = np.random.RandomState(4).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
+        on = parity.run_hip(fv, tex, isz, dict(opts, loose_faces=1), grad)
+        off = parity.run_hip(fv, tex, isz, dict(opts, loose_faces=-1), grad)
+        allp = parity.run_hip(fv, tex, isz, dict(opts, cull=0))
+        for k in ('rgba', 'aggrs_info'):
+            assert np.array_equal(on[k], off[k], equal_nan=True), (name, maker.__name__, k)
+            assert np.array_equal(on[k], allp[k], equal_nan=True), (name, maker.__name__, k, 'all pairs')
+        for k in ('grad_faces', 'grad_textures'):
+            scale = max(1e-30, float(np.abs(off[k]).max()))
+            assert float(np.abs(on[k] - off[k]).max()) <= 2e-5 * scale, (name, maker.__name__, k)
