@@ -390,6 +390,9 @@ def measure(args, wl, dist, dev):
         sampled = {0, args.steps - 1}
         # (the event objects exist before the clock starts: creating one costs the host ~10 us)
         ready = {i: [torch.cuda.Event(enable_timing=True) if (k >= 2 or i == 0) else None for k in range(4)] for i in sampled}
+        import gc
+        gc.collect()
+        gc.disable()                                  # a collection in the middle of 20 steps of 0.24 ms is a 5 % outlier
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -408,6 +411,7 @@ def measure(args, wl, dist, dev):
                 wl.step()
         fence()
         elapsed = time.perf_counter() - t0
+        gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if stub else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

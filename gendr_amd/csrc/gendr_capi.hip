@@ -670,16 +670,16 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     RenderArgs a;
     fill_args(a, workspace, textures, B, nf, T, p);
     // faces with a loose cull box (face_setup_kernel flags them, loose_faces_kernel finds their live pixels): only with a finite
-    // cull radius.  The per-image marks carry a stamp of this call, so that nothing has to be cleared beforehand (whatever the
-    // workspace held: a chance match only makes a workgroup look at its image's flags, which this call did write).
-    static std::atomic<int> stamp_counter{1};
+    // cull radius.  The per-image lists start with a tag word; the binning kernel clears it after use, so a workspace that is
+    // used again -- also by the replay of a captured HIP graph, whose kernel arguments never change -- starts from empty lists,
+    // and fresh memory holds the tag only by a 2^-27 chance (the kernel then ignores face numbers out of range).
     // ... and only for images of at least GENDR_LOOSE_MIN_TILES tiles (1024^2): the extra launch costs 10 us when an image has
     // such a face and 3 us when none has, which at 256^2 is what it saves (C2: forward -5, backward -3, coverage -3 us against
     // +10; a small batch pays without gaining), while at 2048^2 one such face is listed in 65 536 tiles (C5: +8 %).
     const bool loose_on = GENDR_LOOSE_FACES && cull_r < INFINITY && total > 0 && p->cull && p->loose_faces >= 0 &&
                           (p->loose_faces > 0 || (long)a.tiles_per_image >= GENDR_LOOSE_MIN_TILES);
     if (!loose_on) a.loose_flag = nullptr;
-    a.loose_stamp = (stamp_counter.fetch_add(1) & 0x03ffffff) | 0x04000000;      // 27 bits: the list heads hold stamp << 4 | entries
+    a.loose_stamp = 0x05a17c3d;                                                  // 27 bits: the list heads hold tag << 4 | entries
     if (texm == kTexSurface1)
         hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L,
                            const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);

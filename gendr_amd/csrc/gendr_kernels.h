@@ -464,9 +464,9 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         loose = bw > 0.f && bh > 0.f && bw * bh >= GENDR_LOOSE_AREA && bw * bh > 4.f * fw * fh;     // a good part of the image (NDC area 4), four times what the face itself explains
         loose_flag[i] = loose ? 1 : 0;
         if (loose) {
-            // append to the image's list: [0] = (this call's stamp << 4 | entries), [1 ..] the faces.  The stamp makes a
-            // counter of its own call out of whatever the word held (nothing is cleared beforehand); a full list leaves
-            // the face its whole image (the state before round 3).
+            // append to the image's list: [0] = (tag << 4 | entries), [1 ..] the faces.  The tag tells a list head from whatever
+            // fresh memory holds; the binning kernel empties the list after use.  A full list leaves the face its whole image
+            // (the state before round 3).
             int* list = loose_image + (i / nf) * kLooseList;
             int slot = -1;
             for (int cur = __hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);;) {
@@ -637,6 +637,10 @@ __global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GEN
     // did it until round 3 and paid 2.6 us for it: its waves run alone on their SIMDs)
     for (long q = (long)blockIdx.x * kBinThreads + threadIdx.x; q < clear_quads; q += (long)gridDim.x * kBinThreads)
         clear4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the lists of faces with a loose cull box have been used (loose_faces_kernel ran before this launch): empty them for the
+    // next call on this workspace
+    if (a.loose_flag && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.B; i += kBinThreads) a.loose_image[(long)i * kLooseList] = 0;
     __shared__ unsigned long long s_words[64][kBinGroup + 1];
     __shared__ int s_listed[64];
     GENDR_SPAN_BEGIN;
@@ -1252,6 +1256,7 @@ __global__ __launch_bounds__(kThreads) void loose_faces_kernel(const RenderArgs 
             for (int t = (w - base) & (G - 1); t < tasks; t += G) {
                 const int k = (int)((unsigned)t / (unsigned)nchunks), ch = t - k * nchunks;
                 const int f = k == 0 ? f1 : (k == 1 ? f2 : (k == 2 ? f3 : __builtin_amdgcn_readfirstlane(a.loose_image[(long)b * kLooseList + 1 + k])));
+                if ((unsigned)f >= (unsigned)a.nf) continue;                 // (a list head that only looked like one: fresh memory)
                 float r[kRecStage3];
                 load_record<0, kRecStage3>(r, recs + (long)f * REC);
                 int c_lo = 0x7fffffff, c_hi = -1, r_lo = 0x7fffffff, r_hi = -1;

@@ -221,3 +221,36 @@ def test_loose_face_boxes_change_nothing(native_lib, name, opts):
         for k in ('grad_faces', 'grad_textures'):
             scale = max(1e-30, float(np.abs(off[k]).max()))
             assert float(np.abs(on[k] - off[k]).max()) <= 2e-5 * scale, (name, maker.__name__, k)
+
+
+def test_loose_face_lists_survive_graph_replay(native_lib):
+    """The per-image lists of loose faces are emptied by the binning kernel after use, so the replay of a captured HIP graph --
+    same kernel arguments, same workspace, over and over -- starts every time from empty lists (a per-call stamp, the first
+    design, made them grow by the image's faces with every replay until they were full)."""
+    from gendr_amd.functional import renderer as R
+    fv, tex = scenes.slivers()
+    isz = 64
+    o, extra = parity.split_options(dict(loose_faces=1))
+    p = parity.hip_params(isz, o, extra)
+    Bn, nf = fv.shape[:2]
+    faces = torch.from_numpy(fv).reshape(Bn, nf, 9).cuda().contiguous()
+    t = torch.from_numpy(tex).cuda().contiguous()
+    want, _, _ = R.native_forward(faces, t, p)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        R.native_forward(faces, t, p)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rgba, aux, ws = R.native_forward(faces, t, p)
+    for _ in range(40):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(rgba, want)
+    w = ws.cpu().numpy()
+    a256 = lambda v: (v + 255) // 256 * 256
+    control_off = len(w) - 24 * 1024 * 4
+    heads = w[control_off - a256(Bn * 16 * 4):control_off].view(np.int32).reshape(-1, 16)[:Bn, 0]
+    assert (heads == 0).all(), heads
