@@ -355,10 +355,17 @@ def measure(args, wl, dist, dev):
     else:
         import gendr_amd.dist as gdist
         launch = args.launch
+        calibrate = False
         if launch == 'auto':
-            launch = 'graph' if wl.B <= 32 else 'eager'
+            # Up to 32 frames per rank a captured graph wins clearly.  Above, the eager step's host work (~165 us on a fast
+            # host, more on others) is close to the GPU's step (~225 us at C2): eager launches are ~4 % faster than a replayed
+            # graph where the host keeps ahead, ~6 % slower where it does not -- so both are timed on a few untimed steps after
+            # the warm-up and the faster one is used for the timed region ("launch" in the output says which).
+            launch = 'graph'
+            calibrate = wl.B > 32
         if launch == 'graph' and wl.cfg.get('gather'):
             launch = 'eager'                          # a collective inside the step: not captured
+            calibrate = False
         graph = None
         for _ in range(args.warmup):
             wl.step()
@@ -381,6 +388,19 @@ def measure(args, wl, dist, dev):
                 sys.stderr.write('bench: graph capture failed (%s); eager launches\n' % (e,))
                 graph = None
                 launch = 'eager'
+            if graph is not None and calibrate:
+                def _timed(fn, n=8):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / n
+                t_graph = min(_timed(graph.replay), _timed(graph.replay))
+                t_eager = min(_timed(wl.step), _timed(wl.step))
+                if t_eager < t_graph:
+                    graph = None
+                    launch = 'eager'
         # Kernel durations come from HIP events around the native calls, recorded live inside the timed region -- but
         # only on TWO of the steps, the first and the last: a timed event serialises the launches around it (about 10 us each on
         # this stack; four per step cost 11 % of the throughput when every step carried them), and in the middle of the loop it

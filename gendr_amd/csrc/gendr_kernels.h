@@ -267,7 +267,7 @@ struct RenderArgs {
     float* det_partial;
     int resident_q;             // waves of the launched render kernel the chip holds at once, per tile queue (sub-tile split)
     // faces whose cull box is loose (see loose_faces_kernel): per face a flag and the box of its live pixels (columns
-    // lo / hi, rows lo / hi; empty: lo > hi), per image a stamp (== loose_stamp: the image has such faces in THIS call)
+    // lo / hi, rows lo / hi; empty: lo > hi), per image a list of kLooseList ints: (loose_stamp << 4 | entries), then the faces
     const int*  loose_flag;
     int4*       loose_box;
     int*        loose_image;
@@ -1207,7 +1207,7 @@ __device__ __forceinline__ unsigned long long collect_pairs(const TileCtx& t, Re
 // faces with a loose cull box (face_setup_kernel): the bounding box of the pixels that can contribute
 // ---------------------------------------------------------------------------------------------
 // A fixed grid of one-wave workgroups.  The face_setup kernel left, per image, a short list of its flagged faces behind a
-// stamp of this call (loose_image, kLooseList ints per image).  Every wave looks at the lists of all images (lane = image)
+// tag word (loose_image, kLooseList ints per image; emptied by the binning kernel after use).  Every wave looks at the lists of all images (lane = image)
 // and, for the few images that have one, takes every kLooseWaves-th block of 64 consecutive pixels for every listed face:
 // lane = pixel, the face's record arrives by scalar loads, and the pixel is LIVE if it passes the record's (loose) box and is
 // inside the face or the closest-point search of the render kernels -- barycentrics() and point_to_face(), the same float
