@@ -407,9 +407,11 @@ def measure(args, wl, dist, dev):
         # also lets the queue run dry, which the host -- only ~15 us per step faster than the GPU at C2 -- takes steps to refill.
         # Sampled steps are always launched eagerly (an event cannot be recorded inside a replayed graph).
         events, coll = [], []
-        sampled = {0, args.steps - 1}
+        # (a replayed graph: the last step only -- a sampled step is launched eagerly, and at 8 frames per rank an eager step costs
+        # the host three replayed ones)
+        sampled = {args.steps - 1} if graph is not None else {0, args.steps - 1}
         # (the event objects exist before the clock starts: creating one costs the host ~10 us)
-        ready = {i: [torch.cuda.Event(enable_timing=True) if (k >= 2 or i == 0) else None for k in range(4)] for i in sampled}
+        ready = {i: [torch.cuda.Event(enable_timing=True) if (k >= 2 or i == min(sampled)) else None for k in range(4)] for i in sampled}
         import gc
         gc.collect()
         gc.disable()                                  # a collection in the middle of 20 steps of 0.24 ms is a 5 % outlier
