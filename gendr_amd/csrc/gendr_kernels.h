@@ -3,7 +3,8 @@
 // Replaces the three __global__ kernels of the reference
 // (gendr/cuda/generalized_renderer_cuda_kernel.cu = "kernel.cu"):
 //   forward_render_inv_cuda_kernel :620-676  ->  face_setup_kernel (+ face_info_kernel, reference layout)
-//                                                bin_faces_kernel + cover_kernel (new: exact tile culling, per-pixel coverage)
+//                                                bin_faces_kernel + cover_kernel (new: exact tile culling, per-pixel coverage),
+//                                                order_tiles_kernel (heavy tiles first), loose_faces_kernel
 //   forward_render_cuda_kernel     :680-862  ->  render_forward_kernel
 //   backward_render_cuda_kernel    :866-1065 ->  render_backward_kernel
 //
@@ -24,6 +25,11 @@
 //     component) instead of 12..84 per (pixel, face);
 //   * inside the loop every pair still passes the reference's own three skip tests, so culling only removes pairs
 //     that contribute exactly nothing;
+//   * pair hints (round 3): the forward kernel leaves two bits per evaluated pair -- the edge its closest-point search
+//     selected, or "no gradient" -- and the backward kernel evaluates that one edge instead of searching again (same
+//     operations for that edge: bit-identical values), skipping batches and tiles that hold no live pair;
+//   * a face whose cull box is loose (seen edge-on: no error bound) is evaluated once on every pixel of its image
+//     (loose_faces_kernel, images of 1024^2 and more) and binned by the box of the pixels that can contribute;
 //   * everything is wave-local: no workgroup barriers in the render kernels, one wave-tile per workgroup.
 //
 // No MFMA: there is no dense contraction in this path.  Compiled with -ffp-contract=off.

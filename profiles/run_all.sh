@@ -27,5 +27,5 @@ python tools/batch_sweep.py c2 $TAG > $OUT/batch_sweep.log 2>&1
 cp gpurun_out/${TAG}_c2_batch_sweep.json $OUT/ 2>/dev/null
 cp gpurun_out/${TAG}_c2_batch_sweep.json profiles/ 2>/dev/null
 timeout 900 python bench.py --config c2 --steps 30 --warmup 5 2>/dev/null | grep '^{' > $OUT/${TAG}_c2_bench.json
-for c in c3 c4 c5; do [[ " $CFGS " == *" $c "* ]] && timeout 600 python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' > $OUT/${TAG}_${c}_bench.json; done
+for c in c3 c4 c5; do [[ " $CFGS " == *" $c "* ]] && timeout 600 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' > $OUT/${TAG}_${c}_bench.json; done
 ls -la $OUT
