@@ -268,8 +268,16 @@ class GenDRFunction(Function):
         # (kernel.cu:1102,1117,1189); everything else in float32
         compute = torch.float64 if face_vertices.dtype == torch.float64 else torch.float32
         ctx.compute_dtype = compute
-        faces = face_vertices.detach().reshape(B, nf, 9).to(compute).contiguous()
-        tex = textures.detach().to(device=faces.device, dtype=compute).contiguous()
+        # (the usual case -- float32, contiguous, one device -- takes the short way: every tensor op is 1-2 us of host time, and
+        # the eager step of the headline bench is host-bound on a slow host)
+        if face_vertices.dtype == compute and face_vertices.is_contiguous():
+            faces = face_vertices.detach().view(B, nf, 9)
+        else:
+            faces = face_vertices.detach().reshape(B, nf, 9).to(compute).contiguous()
+        if textures.dtype == compute and textures.is_contiguous() and textures.device == faces.device:
+            tex = textures.detach()
+        else:
+            tex = textures.detach().to(device=faces.device, dtype=compute).contiguous()
         if tex.dim() != 4 or tex.shape[0] != B or tex.shape[1] != nf or tex.shape[3] != 3:
             raise ValueError('textures must be [B, nf, T, 3] matching face_vertices [B, nf, 3, 3]; got %s and %s'
                              % (tuple(textures.shape), tuple(face_vertices.shape)))
