@@ -674,7 +674,7 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     // used again -- also by the replay of a captured HIP graph, whose kernel arguments never change -- starts from empty lists,
     // and fresh memory holds the tag only by a 2^-27 chance (the kernel then ignores face numbers out of range).
     // ... and only for images of at least GENDR_LOOSE_MIN_TILES tiles (1024^2): the extra launch costs 10 us when an image has
-    // such a face and 3 us when none has, which at 256^2 is what it saves (C2: forward -5, backward -3, coverage -3 us against
+    // such a face and 5 us when none has, which at 256^2 is what it saves (C2: forward -5, backward -3, coverage -3 us against
     // +10; a small batch pays without gaining), while at 2048^2 one such face is listed in 65 536 tiles (C5: +8 %).
     const bool loose_on = GENDR_LOOSE_FACES && cull_r < INFINITY && total > 0 && p->cull && p->loose_faces >= 0 &&
                           (p->loose_faces > 0 || (long)a.tiles_per_image >= GENDR_LOOSE_MIN_TILES);

@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--modes', default='normal,offscreen(scan only),nocull')
     ap.add_argument('--deterministic', action='store_true', help='gendr_params.deterministic = 1 (per-face backward, no atomics)')
+    ap.add_argument('--loose', type=int, default=0, help='gendr_params.loose_faces: 0 automatic, 1 on, -1 off')
+    ap.add_argument('--hints', type=int, default=0, help='gendr_params.pair_hints: 0 automatic, 1 on, -1 off')
     args = ap.parse_args()
     cfg = B.CONFIGS[args.config]
     Bn = args.batch or cfg['batch']
@@ -52,7 +54,7 @@ def main():
             continue
         if name not in args.modes.split(','):
             continue
-        p = parity.hip_params(isz, o, dict(extra, cull=cull, deterministic=1 if args.deterministic else 0))
+        p = parity.hip_params(isz, o, dict(extra, cull=cull, deterministic=1 if args.deterministic else 0, loose_faces=args.loose, pair_hints=args.hints))
         f = fv.clone(); f[..., 0] += shift
         faces = f.reshape(Bn, -1, 9).to(dev).contiguous()
         t = tex.to(dev).contiguous()
