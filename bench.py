@@ -417,25 +417,27 @@ def measure(args, wl, dist, dev):
         import gc
         gc.collect()
         gc.disable()                                  # a collection in the middle of 20 steps of 0.24 ms is a 5 % outlier
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            if i in sampled and wl.B > 0:
-                e = ready[i]
-                if wl.cfg.get('gather'):
-                    gdist.PROFILE_EVENTS = c = []
-                wl.step(e)
-                gdist.PROFILE_EVENTS = None
-                events.append(e)
-                if wl.cfg.get('gather'):
-                    coll.append(c)
-            elif graph is not None:
-                graph.replay()
-            else:
-                wl.step()
-        fence()
-        elapsed = time.perf_counter() - t0
-        gc.enable()
+        try:
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                if i in sampled and wl.B > 0:
+                    e = ready[i]
+                    if wl.cfg.get('gather'):
+                        gdist.PROFILE_EVENTS = c = []
+                    wl.step(e)
+                    gdist.PROFILE_EVENTS = None
+                    events.append(e)
+                    if wl.cfg.get('gather'):
+                        coll.append(c)
+                elif graph is not None:
+                    graph.replay()
+                else:
+                    wl.step()
+            fence()
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if stub else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -3,7 +3,7 @@
 In-tree so that the built library travels with the source snapshot; nothing is
 JIT-compiled at import time.  ``-ffp-contract=off`` is part of the parity
 policy: the kernels reproduce the reference's operation order
-without FMA contraction.
+without FMA contraction (a later ``-ffp-contract=`` of a variant overrides it).
 """
 import os
 import shutil
@@ -16,7 +16,12 @@ LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
 # -DGENDR_EXACT_GRADIENT=1: every gradient-side quotient, the gaussian / gamma densities and the t-conorm partials keep
 # the reference's own rounding and promotions (kernel.cu:1026-1052) -- the parity build SURVEY H1 asks for; the tests
 # and profiles/parity_r03.json compare the two against the oracle (tests/test_gpu_exact_gradient.py).
-VARIANTS = {"default": [], "exact": ["-DGENDR_EXACT_GRADIENT=1"]}
+# "fast" (round 4; gendr_math.h GENDR_FAST_MATH): the reference's formulas, operation order, skip tests and culling, with the
+# per-pair arithmetic at hardware accuracy (float reciprocals, v_sqrt_f32, 2^x-based exp, float instead of double
+# sub-expressions) and FMA contraction ON -- what nvcc does to the reference by default (/root/reference/setup.py:10).
+# Gated on the GPU by the spread of the reference's own two builds (tests/test_gpu_fast_variant.py); never the silent
+# default: GENDR_VARIANT=fast or _native.use_variant('fast') select it, bench.py reports it under extra.fast_variant.
+VARIANTS = {"default": [], "exact": ["-DGENDR_EXACT_GRADIENT=1"], "fast": ["-DGENDR_FAST_MATH=1", "-ffp-contract=fast"]}
 
 
 def lib_path(variant="default"):

@@ -274,6 +274,7 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.r_zrange = 1. / (double)(p->far_ - p->near_);              // float subtraction first, as kernel.cu:826
     a.r_nzrange = 1. / (double)(p->near_ - p->far_);             // kernel.cu:1026
     a.r_is = 1. / (double)p->image_size;
+    a.rf_scale = (float)a.r_scale; a.rf_gamma = (float)a.r_gamma; a.rf_zrange = (float)a.r_zrange; a.rf_nzrange = (float)a.r_nzrange;
     if (p->dist_func == kGamma || p->dist_func == kGammaRev) {   // kernel.cu:309,:420-421: the pair-independent factors, in double
         a.gamma_k0 = (float)(1. / tgamma((double)p->dist_shape + 1.));
         a.gamma_pdf_c = pow(1. / (double)p->dist_scale, (double)p->dist_shape) / tgamma((double)p->dist_shape);

@@ -123,7 +123,6 @@ typedef float f4v  __attribute__((ext_vector_type(4), aligned(4)));
 
 typedef float f2v  __attribute__((ext_vector_type(2), aligned(4)));
 typedef int   i4v  __attribute__((ext_vector_type(4)));
-typedef float mf4  __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f32_16x16x4_f32
 
 // Floats [BEGIN, END) of a face record -> dst[BEGIN..END) with the widest scalar loads that fit
 // (s_load_dwordx16 / x8 / x4 / x2): one wait per stage instead of one per field.
@@ -154,10 +153,23 @@ __device__ __forceinline__ void load_record(float* dst, RecPtr r)
     }
 }
 
-// double stored in two consecutive floats of the face record (see div_by() in gendr_math.h)
-__device__ __forceinline__ double rec_double(const float* r, int k)
+// reciprocal of a per-face divisor in two consecutive floats of the face record (see div_by() in gendr_math.h): the
+// correctly rounded double; fast build: its float rounding in the first of the two
+__device__ __forceinline__ rcp_t rec_rcp(const float* r, int k)
 {
+#if GENDR_FAST_DEV
+    return r[k];
+#else
     return __hiloint2double(__float_as_int(r[k + 1]), __float_as_int(r[k]));
+#endif
+}
+__device__ __forceinline__ void put_rcp(float* r, int k, double v)
+{
+#if GENDR_FAST_DEV
+    r[k] = (float)v; r[k + 1] = 0.f;
+#else
+    r[k] = __int_as_float(__double2loint(v)); r[k + 1] = __int_as_float(__double2hiint(v));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -290,16 +302,29 @@ struct RenderArgs {
     double r_is;                // 1 / image_size          (kernel.cu:718-719)
     float  gamma_k0;            // gamma family constants, see DistParams
     double gamma_pdf_c;
+    float  rf_scale, rf_gamma, rf_zrange, rf_nzrange;   // the same reciprocals rounded to float (fast build, see rcp_t)
 };
+// the per-call reciprocals in the type div_by() takes in this build
+#if GENDR_FAST_DEV
+#define GENDR_R_SCALE(a)   ((a).rf_scale)
+#define GENDR_R_GAMMA(a)   ((a).rf_gamma)
+#define GENDR_R_ZRANGE(a)  ((a).rf_zrange)
+#define GENDR_R_NZRANGE(a) ((a).rf_nzrange)
+#else
+#define GENDR_R_SCALE(a)   ((a).r_scale)
+#define GENDR_R_GAMMA(a)   ((a).r_gamma)
+#define GENDR_R_ZRANGE(a)  ((a).r_zrange)
+#define GENDR_R_NZRANGE(a) ((a).r_nzrange)
+#endif
 
 // reciprocals of the 31 divisors of gamma's Kummer series -> LDS, once per wave (only the kernels that can meet a gamma
 // distribution carry the table)
 template <int DIST>
-__device__ __forceinline__ const double* gamma_table(double* s_tab, const RenderArgs& a)
+__device__ __forceinline__ const rcp_t* gamma_table(rcp_t* s_tab, const RenderArgs& a)
 {
     if constexpr (DIST == kGamma || DIST == kGammaRev || DIST == -1) {
         const int lane = threadIdx.x & 63;
-        if (lane < kGammaSteps - 1) s_tab[lane] = 1. / (double)(a.p.dist_shape + (float)(lane + 1));
+        if (lane < kGammaSteps - 1) s_tab[lane] = (rcp_t)(1. / (double)(a.p.dist_shape + (float)(lane + 1)));
         __builtin_amdgcn_wave_barrier();
         return s_tab;
     } else {
@@ -320,6 +345,7 @@ struct FaceGeom {
 // reference arithmetic of kernel.cu:637-675 (float, no contraction)
 __device__ __forceinline__ void face_geometry(const float* f, FaceGeom& g)
 {
+#pragma clang fp contract(off)      // in every build variant: faces_info stays bit for bit the reference's (per face, not per pair)
     const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
     const float adj[9] = {
         y1 - y2, x2 - x1, x1 * y2 - x2 * y1,
@@ -523,11 +549,9 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         float a[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) { a[j] = g.sym[3 * k + j] - g.sym[3 * k1 + j]; r[kRecEdge + 3 * k + j] = a[j]; }
-        const double rden = 1. / (double)(a[k] - a[k1]);
-        r[kRecRDen + 2 * k] = __int_as_float(__double2loint(rden)); r[kRecRDen + 2 * k + 1] = __int_as_float(__double2hiint(rden));
+        put_rcp(r, kRecRDen + 2 * k, 1. / (double)(a[k] - a[k1]));
         r[kRecXY + 2 * k] = f[3 * k]; r[kRecXY + 2 * k + 1] = f[3 * k + 1];
-        const double rz = 1. / (double)f[3 * k + 2];
-        r[kRecRZ + 2 * k] = __int_as_float(__double2loint(rz)); r[kRecRZ + 2 * k + 1] = __int_as_float(__double2hiint(rz));
+        put_rcp(r, kRecRZ + 2 * k, 1. / (double)f[3 * k + 2]);
     }
     if (TEXM == kTexSurface1 && in_range) {
         const long nxt = (i + 1 < total_faces) ? i + 1 : i;   // reference reads the next face's texel (:179-182); none after the last
@@ -579,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void face_info_kernel(const float* __rest
 // (and div_by() reproduces that float division exactly).
 __device__ __forceinline__ float pixel_coord(int idx, int is, double r_is)
 {
-    return div_by((float)(2 * idx + 1 - is), r_is);              // r_is = RN(1 / (double)is), computed once on the host
+    return (float)((double)(float)(2 * idx + 1 - is) * r_is);    // r_is = RN(1 / (double)is), computed once on the host; exact in every build (per tile, not per pair)
 }
 
 // box = (xlo, xhi, ylo, yhi).  A rectangle of pixel centres misses the box iff every centre fails the
@@ -924,15 +948,15 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp,
                 x2 = r[kRecXY + 4], y2 = r[kRecXY + 5];
     if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
         // edge k joins vertex k and k+1: t0[k] = tv, t0[k+1] = 1 - tv, t0[k+2] = 0, then t0 -= w (:91-105)
-        const float tva = div_by((w0 * r[kRecEdge + 0] + w1 * r[kRecEdge + 1] + w2 * r[kRecEdge + 2] - r[kRecEdge + 1]), rec_double(r, kRecRDen + 0));
+        const float tva = div_by((w0 * r[kRecEdge + 0] + w1 * r[kRecEdge + 1] + w2 * r[kRecEdge + 2] - r[kRecEdge + 1]), rec_rcp(r, kRecRDen + 0));
         const float a0 = tva - w0, a1 = (1 - tva) - w1, a2 = 0.f - w2;
         const float adx = a0 * x0 + a1 * x1 + a2 * x2, ady = a0 * y0 + a1 * y1 + a2 * y2;
         const float ad = adx * adx + ady * ady;
-        const float tvb = div_by((w0 * r[kRecEdge + 3] + w1 * r[kRecEdge + 4] + w2 * r[kRecEdge + 5] - r[kRecEdge + 5]), rec_double(r, kRecRDen + 2));
+        const float tvb = div_by((w0 * r[kRecEdge + 3] + w1 * r[kRecEdge + 4] + w2 * r[kRecEdge + 5] - r[kRecEdge + 5]), rec_rcp(r, kRecRDen + 2));
         const float b0 = 0.f - w0, b1 = tvb - w1, b2 = (1 - tvb) - w2;
         const float bdx = b0 * x0 + b1 * x1 + b2 * x2, bdy = b0 * y0 + b1 * y1 + b2 * y2;
         const float bd = bdx * bdx + bdy * bdy;
-        const float tvc = div_by((w0 * r[kRecEdge + 6] + w1 * r[kRecEdge + 7] + w2 * r[kRecEdge + 8] - r[kRecEdge + 6]), rec_double(r, kRecRDen + 4));
+        const float tvc = div_by((w0 * r[kRecEdge + 6] + w1 * r[kRecEdge + 7] + w2 * r[kRecEdge + 8] - r[kRecEdge + 6]), rec_rcp(r, kRecRDen + 4));
         const float c0 = (1 - tvc) - w0, c1 = 0.f - w1, c2 = tvc - w2;
         const float cdx = c0 * x0 + c1 * x1 + c2 * x2, cdy = c0 * y0 + c1 * y1 + c2 * y2;
         const float cd = cdx * cdx + cdy * cdy;
@@ -973,12 +997,12 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp,
     const float E00 = r[kRecEdge + 0], E01 = r[kRecEdge + 1], E02 = r[kRecEdge + 2];
     const float E10 = r[kRecEdge + 3], E11 = r[kRecEdge + 4], E12 = r[kRecEdge + 5];
     const float E20 = r[kRecEdge + 6], E21 = r[kRecEdge + 7], E22 = r[kRecEdge + 8];
-    const double D0 = rec_double(r, kRecRDen + 0), D1 = rec_double(r, kRecRDen + 2), D2 = rec_double(r, kRecRDen + 4);
+    const rcp_t D0 = rec_rcp(r, kRecRDen + 0), D1 = rec_rcp(r, kRecRDen + 2), D2 = rec_rcp(r, kRecRDen + 4);
     const float A0 = e0 ? E00 : (e1 ? E10 : E20);
     const float A1 = e0 ? E01 : (e1 ? E11 : E21);
     const float A2 = e0 ? E02 : (e1 ? E12 : E22);
     const float Av1 = e0 ? A1 : (e1 ? A2 : A0);   // a0[v1]
-    const double rden = e0 ? D0 : (e1 ? D1 : D2);
+    const rcp_t rden = e0 ? D0 : (e1 ? D1 : D2);
     const float tv = div_by(w0 * A0 + w1 * A1 + w2 * A2 - Av1, rden);
     const float ta = fminf(fmaxf(tv, 0.f), 1.f);           // min(max(t, 0.), 1.) : the clamp is exact in either precision
     const float tb = fminf(fmaxf(1 - tv, 0.f), 1.f);
@@ -1006,12 +1030,12 @@ __device__ __forceinline__ void point_to_face_edge(Pair& q, const float* r, bool
     const float E00 = r[kRecEdge + 0], E01 = r[kRecEdge + 1], E02 = r[kRecEdge + 2];
     const float E10 = r[kRecEdge + 3], E11 = r[kRecEdge + 4], E12 = r[kRecEdge + 5];
     const float E20 = r[kRecEdge + 6], E21 = r[kRecEdge + 7], E22 = r[kRecEdge + 8];
-    const double D0 = rec_double(r, kRecRDen + 0), D1 = rec_double(r, kRecRDen + 2), D2 = rec_double(r, kRecRDen + 4);
+    const rcp_t D0 = rec_rcp(r, kRecRDen + 0), D1 = rec_rcp(r, kRecRDen + 2), D2 = rec_rcp(r, kRecRDen + 4);
     const float A0 = e0 ? E00 : (e1 ? E10 : E20);
     const float A1 = e0 ? E01 : (e1 ? E11 : E21);
     const float A2 = e0 ? E02 : (e1 ? E12 : E22);
     const float Av1 = e0 ? A1 : (e1 ? A2 : A0);
-    const double rden = e0 ? D0 : (e1 ? D1 : D2);
+    const rcp_t rden = e0 ? D0 : (e1 ? D1 : D2);
     const float tv = div_by(w0 * A0 + w1 * A1 + w2 * A2 - Av1, rden);
     const float ta = inside ? tv : fminf(fmaxf(tv, 0.f), 1.f);
     const float tb = inside ? 1 - tv : fminf(fmaxf(1 - tv, 0.f), 1.f);
@@ -1083,9 +1107,9 @@ __device__ __forceinline__ float clip_and_depth(const Pair& q, const float* r, f
     // max(sum, 1e-5) with a double literal, stored as float: (float)1e-5 lies below 1e-5, so s > 1e-5 iff s > (float)1e-5
     static_assert((double)(float)1e-5 < 1e-5, "the float compare needs RN(1e-5) < 1e-5");
     s = (s > (float)1e-5) ? s : (float)1e-5;
-    const double rs = rcp_for_div_by((double)s);           // three float quotients by one float divisor (s >= 1e-5)
+    const rcp_t rs = rcp_for_div_by(s);           // three float quotients by one float divisor (s >= 1e-5)
     wc[0] = div_by(wc[0], rs); wc[1] = div_by(wc[1], rs); wc[2] = div_by(wc[2], rs);
-    return rcp_rn(div_by(wc[0], rec_double(r, kRecRZ + 0)) + div_by(wc[1], rec_double(r, kRecRZ + 2)) + div_by(wc[2], rec_double(r, kRecRZ + 4)));   // "1. /": one rounding
+    return rcp_rn(div_by(wc[0], rec_rcp(r, kRecRZ + 0)) + div_by(wc[1], rec_rcp(r, kRecRZ + 2)) + div_by(wc[2], rec_rcp(r, kRecRZ + 4)));   // "1. /": one rounding
 }
 
 // surface texel index for clipped barycentrics (kernel.cu:179-185); may be >= T (reference quirk)
@@ -1592,8 +1616,8 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
-    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` is one plane [B,is,is], nothing else is written
@@ -1741,7 +1765,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
                                                    : (inside_closed(q) && (a.p.double_side || front));  // :816
                     if (eligible) {
                         res.flags |= kFlagRgb;
-                        res.z = rgb_soft ? div_by(a.p.far_ - zp, a.r_zrange) : zp;   // zp_norm (:826) or zp
+                        res.z = rgb_soft ? div_by(a.p.far_ - zp, GENDR_R_ZRANGE(a)) : zp;   // zp_norm (:826) or zp
                         float cc[3]; int own;
                         sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
                         res.c0 = cc[0]; res.c1 = cc[1]; res.c2 = cc[2];
@@ -1794,7 +1818,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
                 const float zn = res.z;
                 // exp_delta_zp and exp_z of :827-832: one of the two is exp(0) == 1 exactly
                 const bool deeper = zn > smax;
-                const float e = expf(div_by(deeper ? smax - zn : zn - smax, a.r_gamma));
+                const float e = exp_f(div_by(deeper ? smax - zn : zn - smax, GENDR_R_GAMMA(a)));
                 const float edz = deeper ? e : 1.f;
                 const float ez = deeper ? 1.f : e;
                 if (deeper) smax = zn;
@@ -1835,7 +1859,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             aux[P] = (float)face_min;
         } else {
 #pragma unroll
-            for (int k = 0; k < 3; k++) out[k * P] = col[k] / ssum;
+            for (int k = 0; k < 3; k++) out[k * P] = div_f(col[k], ssum);
             aux[0] = ssum;
             aux[P] = smax;
         }
@@ -1974,8 +1998,8 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
                     }
                 }
             } else if (front || a.p.double_side) {                      // :1006-1030
-                const float zn = div_by(a.p.far_ - zp, a.r_zrange);
-                const float zs = grad_div(q.frag * expf(div_by(zn - px.smax, a.r_gamma)), px.ssum);   // :1010
+                const float zn = div_by(a.p.far_ - zp, GENDR_R_ZRANGE(a));
+                const float zs = grad_div(q.frag * exp_f(div_by(zn - px.smax, GENDR_R_GAMMA(a))), px.ssum);   // :1010
                 float cc[3]; int own;
                 sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
                 float C_rgb = 0.f;
@@ -1994,14 +2018,14 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
                 C_rgb *= zs;                                            // :1023
                 C_xy += grad_div(C_rgb, q.frag);                        // :1024
 #if GENDR_EXACT_GRADIENT
-                const float C_z = div_by(div_by(C_rgb, a.r_gamma), a.r_nzrange) * zp * zp;   // :1026
-                gv[2] = div_by(div_by(C_z * wc[0], rec_double(r, kRecRZ + 0)), rec_double(r, kRecRZ + 0));
-                gv[5] = div_by(div_by(C_z * wc[1], rec_double(r, kRecRZ + 2)), rec_double(r, kRecRZ + 2));
-                gv[8] = div_by(div_by(C_z * wc[2], rec_double(r, kRecRZ + 4)), rec_double(r, kRecRZ + 4));
+                const float C_z = div_by(div_by(C_rgb, GENDR_R_GAMMA(a)), GENDR_R_NZRANGE(a)) * zp * zp;   // :1026
+                gv[2] = div_by(div_by(C_z * wc[0], rec_rcp(r, kRecRZ + 0)), rec_rcp(r, kRecRZ + 0));
+                gv[5] = div_by(div_by(C_z * wc[1], rec_rcp(r, kRecRZ + 2)), rec_rcp(r, kRecRZ + 2));
+                gv[8] = div_by(div_by(C_z * wc[2], rec_rcp(r, kRecRZ + 4)), rec_rcp(r, kRecRZ + 4));
 #else
                 // C_rgb / gamma / (near - far) * zp^2 * w_k / z_k^2 with the float reciprocals (:1026-1029)
                 const float C_z = C_rgb * ((float)a.r_gamma * (float)a.r_nzrange) * zp * zp;
-                const float rz0 = (float)rec_double(r, kRecRZ + 0), rz1 = (float)rec_double(r, kRecRZ + 2), rz2 = (float)rec_double(r, kRecRZ + 4);
+                const float rz0 = (float)rec_rcp(r, kRecRZ + 0), rz1 = (float)rec_rcp(r, kRecRZ + 2), rz2 = (float)rec_rcp(r, kRecRZ + 4);
                 gv[2] = C_z * wc[0] * (rz0 * rz0);
                 gv[5] = C_z * wc[1] * (rz1 * rz1);
                 gv[8] = C_z * wc[2] * (rz2 * rz2);
@@ -2029,7 +2053,7 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
                     const float len = q.dis;   // == sqrtf(dx*dx + dy*dy): the very value soft_fragment() computed (:771)
 #if GENDR_EXACT_GRADIENT
                     if ((double)len >= 1e-6) {
-                        const double rlen = rcp_for_div_by((double)len);
+                        const rcp_t rlen = rcp_for_div_by(len);
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
                             gv[3 * k + 0] = div_by(q.sign * C_xy * tw[k] * q.dx, rlen);
@@ -2109,8 +2133,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
 
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
-    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
@@ -2449,8 +2473,8 @@ __device__ __forceinline__ void render_backward_faces_body(const RenderArgs& a, 
     constexpr int REC = record_floats(TEXM);
     constexpr int NG = GradSlots<TEXM>::n;
     const int lane = threadIdx.x & 63;
-    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
     // Workgroups are dispatched round-robin over the 8 XCDs: XCD x takes the images x, x + 8, ... one after the other, so
     // that the planes of the image its waves are gathering from stay in that XCD's L2.
     const int xcd = blockIdx.x & 7;
@@ -2463,6 +2487,7 @@ __device__ __forceinline__ void render_backward_faces_body(const RenderArgs& a, 
     // A box that takes many steps -- a sliver whose cull box degenerated to a large part of the image (23 of the 81920 faces
     // of the headline batch, but one wavefront scanning 256^2 pixels alone takes as long as all the others together) -- is
     // left to the band kernel, which cuts it into bands of kDetBandRows rows.
+    bool by_bands = false;
     if ((TEXM != kTexSurfaceN || RGB == kRgbNone) && a.det_list) {
         const int wp = min(d.W, 64), rows_per_step = 64 / wp;
         const long steps = (long)((d.yi1 - d.yi0) / rows_per_step + 1) * ((d.W + wp - 1) / wp);
@@ -2474,16 +2499,32 @@ __device__ __forceinline__ void render_backward_faces_body(const RenderArgs& a, 
                 if (lane == 0) a.det_list[at] = (int)face_lin;
                 return;
             }
+            // The list is full (which faces found a slot depends on the order the waves arrived in): this wave walks the
+            // face itself, but band by band and summing the bands in ascending order -- the very sums, in the very order,
+            // the band kernel and det_reduce_kernel form -- so the gradient does not depend on who got a slot.
+            by_bands = true;
         }
     }
     float rec[REC];
     load_record<0, REC>(rec, (RecPtr)a.records + face_lin * REC);         // the whole record, wave-uniform: scalar loads
     float acc[NG];
+    float mine = 0.f;
+    if (by_bands) {
+        const int nbands = (a.is + kDetBandRows - 1) / kDetBandRows;
+        for (int band = 0; band < nbands; band++) {
 #pragma unroll
-    for (int k = 0; k < NG; k++) acc[k] = 0.f;
-    det_rows<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, rec, b, fn, face_lin, d.x0, d.W, d.yi0, d.yi1, acc);
-    // lane k adds component k to the gradient -- one read-modify-write round trip for all of them
-    const float mine = det_combine<NG>(acc);
+            for (int k = 0; k < NG; k++) acc[k] = 0.f;
+            const int ya = max(d.yi0, band * kDetBandRows), yb = min(d.yi1, band * kDetBandRows + kDetBandRows - 1);
+            if (ya <= yb) det_rows<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, rec, b, fn, face_lin, d.x0, d.W, ya, yb, acc);
+            mine += det_combine<NG>(acc);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NG; k++) acc[k] = 0.f;
+        det_rows<DIST, ALPHA, RGB, SQ, TEXM>(a, dp, rec, b, fn, face_lin, d.x0, d.W, d.yi0, d.yi1, acc);
+        // lane k adds component k to the gradient -- one read-modify-write round trip for all of them
+        mine = det_combine<NG>(acc);
+    }
     if (lane < NG) {
         float* dst = lane < 9 ? a.grad_faces + face_lin * 9 + lane : a.grad_textures + face_lin * (NG - 9) + (lane - 9);
         *dst += mine;
@@ -2498,8 +2539,8 @@ __device__ __forceinline__ void render_backward_bands_body(const RenderArgs& a, 
     constexpr int REC = record_floats(TEXM);
     constexpr int NG = GradSlots<TEXM>::n;
     const int lane = threadIdx.x & 63;
-    __shared__ double s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, a.r_scale, a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
     const int n = min(__builtin_amdgcn_readfirstlane(*a.det_count), kDetBigCap);
     const int nbands = (a.is + kDetBandRows - 1) / kDetBandRows;
     const long items = (long)n * nbands;

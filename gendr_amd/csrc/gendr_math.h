@@ -18,7 +18,32 @@
 
 #define GENDR_HD __host__ __device__ __forceinline__
 
+// Build variant "fast" (gendr_amd/build.py VARIANTS: -DGENDR_FAST_MATH=1 -ffp-contract=fast; libgendr_hip_fast.so).  The
+// default build reproduces the reference's ROUNDING operation by operation (correctly rounded quotients through double
+// reciprocals, correctly rounded sqrt / reciprocal, the library's expf, no contraction); the fast build keeps the
+// reference's FORMULAS, operation order, fold order, skip tests and culling, and computes the per-pair arithmetic the way a
+// compiler with contraction on (nvcc's default for the reference, /root/reference/setup.py:10) and 1-ulp hardware
+// estimates would: a * (1/b) with a float reciprocal (<= 1 ulp), v_sqrt_f32, v_rcp_f32 + one Newton step, 2^x-based exp
+// (~2 ulp), float instead of double sub-expressions.  It is gated on the GPU by the spread of the reference's OWN two
+// builds (oracle/_ref render vs render_fma: tests/test_gpu_fast_variant.py) and never substituted silently
+// (GENDR_VARIANT=fast / _native.use_variant('fast')).  Device code only: the host scalar exports stay exact.
+#ifndef GENDR_FAST_MATH
+#define GENDR_FAST_MATH 0
+#endif
+#if GENDR_FAST_MATH && defined(__HIP_DEVICE_COMPILE__)
+#define GENDR_FAST_DEV 1
+#else
+#define GENDR_FAST_DEV 0
+#endif
+
 namespace gendr {
+
+// the type a wave-uniform (or per-face) divisor's reciprocal is kept in: see div_by()
+#if GENDR_FAST_DEV
+typedef float rcp_t;
+#else
+typedef double rcp_t;
+#endif
 
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kProbThreshold = 0.000001;   // kernel.cu:13
@@ -40,16 +65,16 @@ struct DistParams {
     float scale;   // tau
     float shape;   // p of gamma
     float shift;   // shift (in units of tau) of the one-sided families
-    double rscale; // RN_double(1 / (double)scale), see div_by()
+    rcp_t rscale;  // RN_double(1 / (double)scale), see div_by()
     // gamma family: what does not depend on the pair, computed once per call on the host (kernel.cu:309,:420-421)
     float  gamma_k0;       // (float)(1. / tgamma(shape + 1.)), first Kummer term
     double gamma_pdf_c;    // pow(1. / scale, shape) / tgamma(shape)
-    const double* gamma_r; // gamma_r[i - 1] = RN_double(1 / (double)(shape + i)), i = 1..31, or NULL: divide
+    const rcp_t* gamma_r;  // gamma_r[i - 1] = RN_double(1 / (double)(shape + i)), i = 1..31, or NULL: divide
 };
 
 GENDR_HD DistParams make_dist_params(float scale, float shape, float shift)
 {
-    DistParams d = {scale, shape, shift, 1. / (double)scale,
+    DistParams d = {scale, shape, shift, (rcp_t)(1. / (double)scale),
                     (float)(1. / tgamma((double)shape + 1.)), pow(1. / (double)scale, (double)shape) / tgamma((double)shape), nullptr};
     return d;
 }
@@ -58,20 +83,33 @@ GENDR_HD DistParams make_dist_params(float scale, float shape, float shift)
 // (a float quotient is never within 2^-49 relative of a float rounding midpoint; the double product is within
 // 2^-52 of a / b; 0, inf and NaN divisors behave as IEEE division).  Used for divisors that are uniform over
 // a wavefront: three fp64-rate instructions instead of the IEEE f32 division expansion.
-GENDR_HD float div_by(float a, double rb) { return (float)((double)a * rb); }
+// Fast build: rb is the float reciprocal (rounded from the double one, or v_rcp_f32 + one Newton step): one multiply,
+// <= 1 ulp.
+GENDR_HD float div_by(float a, rcp_t rb)
+{
+#if GENDR_FAST_DEV
+    return a * rb;
+#else
+    return (float)((double)a * rb);
+#endif
+}
 
 // Reciprocal of a positive, finite, normal double for use with div_by(): the argument above leaves 2^-49 - 2^-52 of
 // slack, so rb may be off by a few ulps.  On the device: v_rcp_f64 and two Newton steps (error < 2 ulp, 5
 // instructions) instead of the IEEE f64 division expansion (~15); on the host the true quotient.
-GENDR_HD double rcp_for_div_by(double b)
+GENDR_HD rcp_t rcp_for_div_by(float bf)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if GENDR_FAST_DEV
+    const float y = __builtin_amdgcn_rcpf(bf);
+    return __builtin_fmaf(__builtin_fmaf(-bf, y, 1.f), y, y);
+#elif defined(__HIP_DEVICE_COMPILE__)
+    const double b = (double)bf;
     double r = __builtin_amdgcn_rcp(b);
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
     return r;
 #else
-    return 1. / b;
+    return 1. / (double)bf;
 #endif
 }
 
@@ -84,7 +122,9 @@ GENDR_HD double rcp_for_div_by(double b)
 // (tests/test_gpu_exact_math.py); outside that range, and for 0 / inf / NaN, the compiler's expansion is used.
 GENDR_HD float sqrt_rn(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if GENDR_FAST_DEV
+    return __builtin_amdgcn_sqrtf(x);                        // v_sqrt_f32: 1 ulp
+#elif defined(__HIP_DEVICE_COMPILE__)
     if (!(x >= 0x1p-96f && x <= 0x1p+96f)) return sqrtf(x);
     const float y = __builtin_amdgcn_rsqf(x);
     float g = x * y;                                         // ~ sqrt(x)
@@ -100,7 +140,11 @@ GENDR_HD float sqrt_rn(float x)
 }
 GENDR_HD float rcp_rn(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if GENDR_FAST_DEV
+    // v_rcp_f32 (1 ulp), one Newton step, and v_div_fixup_f32 for what the step turns into NaN (0, inf): 1 / x as IEEE has it
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-x, y0, 1.f), y0, y0), x, 1.f);
+#elif defined(__HIP_DEVICE_COMPILE__)
     if (!(fabsf(x) >= 0x1p-96f && fabsf(x) <= 0x1p+96f)) return 1.f / x;
     float y = __builtin_amdgcn_rcpf(x);
     y = __builtin_fmaf(__builtin_fmaf(-x, y, 1.f), y, y);
@@ -142,10 +186,53 @@ GENDR_HD float grad_div(float a, float b)
 #endif
 }
 
+// exp of the pair math.  Fast build: exp(x) = 2^(x log2 e) with the product in two pieces -- ph, and pl = the rounding
+// error of ph plus the tail of log2 e -- the hardware 2^ph (v_exp_f32, 1 ulp) and a first-order correction by pl: ~2 ulp
+// for every argument the path meets (the plain 2^(x * log2e) loses |x| * 6e-8 relative), 8 instructions against the
+// library's 47 issue cycles.  Arguments beyond the float exponent range (and +-inf) take the bare 2^ph: 0 resp. inf.
+GENDR_HD float exp_f(float x)
+{
+#if GENDR_FAST_DEV
+    const float ph = x * 0x1.715476p+0f;
+    const float pl = __builtin_fmaf(x, 0x1.4ae0c0p-26f, __builtin_fmaf(x, 0x1.715476p+0f, -ph));
+    const float e = __builtin_amdgcn_exp2f(ph);
+    return __builtin_fabsf(ph) < 126.f ? __builtin_fmaf(e, pl * 0x1.62e430p-1f, e) : e;
+#else
+    return expf(x);
+#endif
+}
+// a / b where the reference writes a float division whose divisor is NOT uniform (t-conorm folds, the colour normalisation):
+// IEEE division in the parity builds; fast build: v_rcp_f32 and one correction step on the quotient (<= 1 ulp)
+GENDR_HD float div_f(float a, float b)
+{
+#if GENDR_FAST_DEV
+    const float y = __builtin_amdgcn_rcpf(b);
+    const float q = a * y;
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-q, b, a), y, q), b, a);   // (0, inf, NaN operands: as IEEE division)
+#else
+    return a / b;
+#endif
+}
+
 GENDR_HD float quiet_nan() { return __builtin_nanf(""); }
 
-// normal CDF of a float argument (kernel.cu:293 calls CUDA's normcdf(float)).
-GENDR_HD float norm_cdf(float u) { return 0.5f * erfcf(-u * 0.70710678118654752440f); }
+// normal CDF of a float argument (kernel.cu:293: `normcdf(sign * x / scale)` on a float).  CUDA resolves that call to its
+// float overload; HIP has no normcdf(float), so the reference's kernel compiled for THIS platform (oracle/build_ref.py)
+// promotes to normcdf(double) and rounds the result.  Device, default build: normcdff (the float function, as under CUDA);
+// `exact` build: the double function rounded to float -- what the pin build of the reference computes here, so that the exact
+// variant agrees with it to 1e-5 on the gaussian option sets too (round 4: the three float forms -- normcdff, 0.5 erfcf(-u /
+// sqrt 2), double rounded -- differ in the last bit, which the saturated einstein partial (1 - A^2) / (1 - D^2) amplifies to
+// 1e-3 of a face-gradient element).  Host (scalar exports; no normcdf there): the erfc form, as the CPU restatement.
+GENDR_HD float norm_cdf(float u)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && GENDR_EXACT_GRADIENT
+    return (float)normcdf((double)u);
+#elif defined(__HIP_DEVICE_COMPILE__)
+    return normcdff(u);
+#else
+    return 0.5f * erfcf(-u * 0.70710678118654752440f);
+#endif
+}
 
 // shifted abscissa of the one-sided families; `rev` mirrors it (kernel.cu:301-308, :339-345, :351-357)
 template <bool REV>
@@ -169,7 +256,11 @@ template <> struct Dist<kUniform> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :270-277
         const float u = div_by(sign * x, d.rscale);
         if (u < -1) return 0.f;
+#if GENDR_FAST_DEV
+        if (u < 1) return __builtin_fmaf(0.5f, u, 0.5f);
+#else
         if (u < 1) return (float)((double)(sign * x) * 0.5 / (double)d.scale + 0.5);
+#endif
         return 1.f;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :391-392
@@ -216,7 +307,7 @@ template <> struct Dist<kGaussian> {
 #if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
         // gradient side (see grad_div): the density to fp32 accuracy, exp in float instead of double
         const float q = div_by(x, d.rscale);
-        return (float)(d.rscale * 0.3989422804014327) * expf(-0.5f * q * q);
+        return (float)(d.rscale * 0.3989422804014327) * exp_f(-0.5f * q * q);
 #else
         const double q = (double)div_by(x, d.rscale);
         return (float)(1. / (double)d.scale / sqrt(2. * kPi) * exp(-0.5 * q * q));
@@ -226,17 +317,21 @@ template <> struct Dist<kGaussian> {
 
 template <> struct Dist<kLaplace> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :263-268
-        const float e = 0.5f * expf(div_by(-x, d.rscale));  // 0.5 * e is exact in either precision
+        const float e = 0.5f * exp_f(div_by(-x, d.rscale));  // 0.5 * e is exact in either precision
         return sign < 0 ? e : 1.f - e;
     }
     static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :388-389
-        return (float)(0.5 / (double)d.scale * (double)expf(div_by(-x, d.rscale)));
+        return (float)(0.5 / (double)d.scale * (double)exp_f(div_by(-x, d.rscale)));
     }
 };
 
 template <> struct Dist<kLogistic> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) {                                // :254-255
-        return (float)(1. / (1. + (double)expf(div_by(-sign * x, d.rscale))));
+#if GENDR_FAST_DEV
+        return rcp_rn(1.f + exp_f(div_by(-sign * x, d.rscale)));
+#else
+        return (float)(1. / (1. + (double)exp_f(div_by(-sign * x, d.rscale))));
+#endif
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :378-380
         const float y = cdf(sign, x, d);
@@ -273,17 +368,17 @@ template <> struct Dist<kReciprocal> {
 };
 
 template <> struct Dist<kGumbelMax> {
-    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return expf(-expf(-sign * x / d.scale)); }   // :329-331
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return exp_f(-exp_f(-sign * x / d.scale)); }   // :329-331
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :429-430
         const float u = sign * x / d.scale;
-        return expf(-(u + expf(-u))) / d.scale;
+        return exp_f(-(u + exp_f(-u))) / d.scale;
     }
 };
 
 template <> struct Dist<kGumbelMin> {
-    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return 1.f - expf(-expf(sign * x / d.scale)); }   // :333-335
+    static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return 1.f - exp_f(-exp_f(sign * x / d.scale)); }   // :333-335
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // :432-433
-        return expf(-((-sign * x / d.scale) + expf(sign * x / d.scale))) / d.scale;
+        return exp_f(-((-sign * x / d.scale) + exp_f(sign * x / d.scale))) / d.scale;
     }
 };
 
@@ -292,14 +387,14 @@ template <bool REV> struct ExponentialFamily {                                  
         if (!REV) { if (sign * x + d.shift * d.scale < 0.f) return 0.f; }
         else      { if (sign * x - d.shift * d.scale > 0.f) return 1.f; }
         const float xs = shifted<REV>(sign, x, d);
-        const float y = 1.f - expf(div_by(-xs, d.rscale));
+        const float y = 1.f - exp_f(div_by(-xs, d.rscale));
         return REV ? 1.f - y : y;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {
         if (!REV) { if (sign * x + d.shift * d.scale < 0.f) return 0.f; }
         else      { if (sign * x - d.shift * d.scale > 0.f) return 0.f; }
         const float xs = shifted<REV>(sign, x, d);
-        return (float)(1. / (double)d.scale * (double)expf(div_by(-xs, d.rscale)));
+        return (float)(1. / (double)d.scale * (double)exp_f(div_by(-xs, d.rscale)));
     }
 };
 template <> struct Dist<kExponential> : ExponentialFamily<false> {};
@@ -320,14 +415,15 @@ template <bool REV> struct GammaFamily {                                        
             factor *= d.gamma_r ? div_by(xr, d.gamma_r[i - 1]) : xr / (d.shape + i);
             kummers += factor;
         }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
+        // (the `exact` build variant calls powf for every shape, like the reference: the parity artefact)
         // shape 1 and 2 (2: the setting of BASELINE config 5): the power is the operand resp. one multiply -- the
         // correctly rounded value, which the library's powf (~100 instructions) reaches to within an ulp
         const float xp = d.shape == 2.f ? xr * xr : (d.shape == 1.f ? xr : powf(xr, d.shape));
 #else
         const float xp = powf(xr, d.shape);
 #endif
-        const float y = xp * expf(div_by(-xs, d.rscale)) * kummers;
+        const float y = xp * exp_f(div_by(-xs, d.rscale)) * kummers;
         return REV ? 1.f - y : y;
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // explicit double in the reference
@@ -341,7 +437,7 @@ template <bool REV> struct GammaFamily {                                        
             if (!REV) { if (sign * x + d.shift * d.scale <= 0.f) return 0.f; }
             else      { if (sign * x - d.shift * d.scale >= 0.f) return 0.f; }
             const float xf = shifted<REV>(sign, x, d);
-            return (float)d.gamma_pdf_c * (d.shape == 2.f ? xf : 1.f) * expf(div_by(-xf, d.rscale));
+            return (float)d.gamma_pdf_c * (d.shape == 2.f ? xf : 1.f) * exp_f(div_by(-xf, d.rscale));
         }
 #endif
         double xs;
@@ -442,7 +538,7 @@ template <> struct TConorm<kProbabilistic> {
     static GENDR_HD float grad_fp32(float A, float b, float) { return grad_div(1.f - A, fmaxf(1.f - b, 1e-6f)); }
 };
 template <> struct TConorm<kEinstein> {
-    static GENDR_HD float fold(float a, float b, float) { return (a + b) / (1 + a * b); }                // :487-488
+    static GENDR_HD float fold(float a, float b, float) { return div_f(a + b, 1 + a * b); }              // :487-488
     static GENDR_HD float grad(float A, float b, float) {                                                // :580-581
         return (float)((1. - (double)(A * A)) / fmax(1. - (double)(b * b), 1e-6));
     }
@@ -476,6 +572,9 @@ template <> struct TConorm<kYager> {
     static GENDR_HD float fold(float a_ex, float b_new, float p) {                                       // :511-519
         if (p <= 0.f) return quiet_nan();
         const float a = 1.f - a_ex, b = 1.f - b_new;
+#if GENDR_FAST_DEV
+        if (p == 2.f) { const float fa = 1.f - a, fb = 1.f - b; return 1.f - fmaxf(0.f, 1.f - sqrt_rn(fa * fa + fb * fb)); }
+#endif
         const double xa = 1. - (double)a, xb = 1. - (double)b;
         // p = 2 (the setting of the reference's benchmark table, train_reconstruction.py:551): pow(x, 2.) is x * x and
         // pow(s, .5) is sqrt(s) up to the last bit of a double -- two multiplies and a square root instead of three pow()
@@ -485,6 +584,9 @@ template <> struct TConorm<kYager> {
     }
     static GENDR_HD float grad(float A, float b, float p) {                                              // :590-592
         if (A == 1.f) return 0.f;
+#if GENDR_FAST_DEV
+        if (p == 2.f) return b * rcp_rn(A);
+#endif
         if (p == 2.f) return (float)((double)b * (1. / (double)A));            // pow(b, 1.) * pow(A, -1.)
         return (float)(pow((double)b, (double)p - 1.) * pow((double)A, 1. - (double)p));
     }

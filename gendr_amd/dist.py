@@ -52,17 +52,13 @@ class _Timed:
         return False
 
 
-_EQUAL_BLOCKS_SEEN = set()      # (group, block size) combinations every rank has already agreed on
-
-
 def _check_equal_blocks(n_local, group):
     """all_gather_into_tensor / reduce_scatter_tensor need the same block size on every rank: unequal blocks hang
-    or corrupt on NCCL / RCCL instead of failing.  One tiny all-reduce (min and max of the local size) and a host read --
-    once per (group, block size): a training loop gathers the same shapes every step, and every rank takes the same
-    branch here (a rank that has seen the size before has seen all ranks agree on it)."""
-    key = (id(group) if group is not None else 0, int(n_local))
-    if key in _EQUAL_BLOCKS_SEEN:
-        return
+    or corrupt on NCCL / RCCL instead of failing.  One tiny all-reduce (min and max of the local size) and a host read on
+    EVERY call: whether to run it must not depend on anything a rank knows by itself (a per-rank cache keyed on the local
+    block size let a ragged step send one rank into the all-gather while another issued this all-reduce -- mismatched
+    collectives, i.e. the hang the check exists to prevent).  Callers that shard evenly pass
+    ``assume_equal_blocks=True`` and skip it."""
     t = torch.tensor([n_local, -n_local], dtype=torch.int64)
     if dist.get_backend(group) != 'gloo':
         t = t.cuda()
@@ -71,7 +67,6 @@ def _check_equal_blocks(n_local, group):
     if lo != hi:
         raise ValueError('gather_views needs equally sized per-rank view blocks (got %d..%d views per rank); '
                          'pad the batch or shard it evenly' % (lo, hi))
-    _EQUAL_BLOCKS_SEEN.add(key)
 
 
 class _GatherViews(torch.autograd.Function):

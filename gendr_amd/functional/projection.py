@@ -42,8 +42,12 @@ def _check_indices(faces, nv):
     if faces.is_cuda and torch.cuda.is_current_stream_capturing():
         return
     key = id(faces)
-    hit = _CHECKED.get(key)
-    if hit is not None and hit[0]() is faces and hit[1] == faces._version and hit[2] <= nv:
+    try:
+        version = faces._version          # inference tensors have no version counter (RuntimeError): always checked
+    except RuntimeError:
+        version = None
+    hit = _CHECKED.get(key) if version is not None else None
+    if hit is not None and hit[0]() is faces and hit[1] == version and hit[2] <= nv:
         return
     lo, hi = torch.aminmax(faces)
     if bool((lo < 0) | (hi >= nv)):
@@ -53,7 +57,8 @@ def _check_indices(faces, nv):
             del _CHECKED[k]
         if len(_CHECKED) > 64:
             _CHECKED.clear()
-    _CHECKED[key] = (weakref.ref(faces), faces._version, nv)
+    if version is not None:
+        _CHECKED[key] = (weakref.ref(faces), version, nv)
 
 
 class ProjectFacesFunction(torch.autograd.Function):

@@ -71,7 +71,9 @@ typedef struct gendr_params {
                                       order (one wavefront per face, no atomics): two calls on the same inputs return
                                       bit-identical gradients.  The reference's atomicAdd order is not fixed
                                       (kernel.cu:1054-1063; experiments/train_reconstruction.py:582-586 warns about it).
-                                      Slower; 0 (default): hardware fp32 atomics, one per (tile batch, face, component). */
+                                      Slower; 0 (default): hardware fp32 atomics, one per (tile batch, face, component).
+                                      Float32 entry points only: gendr_backward_f64 (the reference's double instantiation,
+                                      one fp64 atomic per pair and component like kernel.cu:1054-1063) IGNORES this field. */
     int   skip_unlisted_aux;       /* 1: gendr_forward does not write `aggrs_info` for the 8x8 tiles no face reaches (their
                                       RGBA is still written).  gendr_backward never reads those pixels' aggrs_info, so the
                                       autograd path sets it; a caller that hands aggrs_info out (forward_render of

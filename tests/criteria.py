@@ -1,41 +1,55 @@
-"""Acceptance criterion of the GPU parity tests (DESIGN.md "parity policy").  ELEMENT-WISE since round 3.
+"""Acceptance criterion of the HIP product against the CPU restatement (DESIGN.md "parity policy").  ELEMENT-WISE since
+round 3.  (Against the REFERENCE's own kernels, run on the GPU, the product is held to a FLAT 1e-5 with an enumerated
+exception table: tests/pin.py.  The rule below is what a comparison with a CPU libm needs.)
 
 Target (BASELINE.json north_star): 1e-5 relative against the fp32 oracle.  Every element e of every compared tensor
 has to satisfy
 
-    |hip_e - o32_e|  <=  max( 1e-5 * scale_e ,  K * noise_e )
+    |hip_e - o32_e|  <=  max( 1e-5 * scale_e ,  K_NOISE * noise_e ,  K_FLIP * flip_e )        K_NOISE = 8, K_FLIP = 2
 
     scale_e = max(|o32_e|, 1e-6 * max|o32|)              images (rgba, aggrs_info)
             = max(|o32_e|, sum of |contributions|_e)     gradients: a gradient element is a sum over (pixel, face)
                                                           pairs in an order that differs by design (and from run to
                                                           run: float atomics), so the error is measured against the
                                                           sum of the magnitudes that were added
-    noise_e = what float arithmetic itself does to the reference's formula at e, measured three ways on the oracle:
-              its fp32-vs-fp64 spread |o32 - o64|, and the change of o32 when every single-precision libm result
-              (expf, powf, logf, erfcf, asinf, coshf, atanf) is moved ONE ulp -- all up, all down, and up or
-              down by a hash of the result's bits, so that neighbouring pairs move against each other (`oracle.libm_jitter`:
-              the GPU's libm and glibc are different, equally valid libms).  1 - exp(-e^u), 1 - y, Frank /
-              Aczel-Alsina near alpha -> 0 and the saturated 1e-6 guards amplify that one ulp by 1e3..1e7.  The
-              largest of the three, taken as the maximum over the element's neighbourhood (the 3x3 pixels around it
-              in every channel; the 9 / 3T components of its face): one element's spread is a sample of the noise,
-              not a bound on it.
+    noise_e = what a different but equally valid libm does to the reference's formula at e: the change of o32 when every
+              single-precision libm result (expf, powf, logf, erfcf, asinf, coshf, atanf) is moved ONE ulp -- 14 modes
+              (JITTER_MODES): all up, all down, and up or down by six different hash bits of (result, argument) and their
+              complements, so that neighbouring pairs also move against each other (`oracle.libm_jitter`: the GPU's libm
+              and glibc are different, equally valid libms).  1 - exp(-e^u), 1 - y, Frank / Aczel-Alsina near alpha -> 0 and
+              the saturated 1e-6 guards amplify that one ulp by 1e3..1e7.  The largest of the 14, taken as the maximum
+              over the element's neighbourhood (the 3x3 pixels around it in every channel; the 9 / 3T components of its
+              face): one element's change is a sample of the noise, not a bound on it -- hence also K_NOISE = 8 rather
+              than 1: fourteen samples of a sum of signed one-ulp moves underestimate its worst case (measured in round 3,
+              tools/criteria_study.py: K = 4 left 3 of 97 cases with a handful of violating elements, K = 8 none).
+              The oracle's fp32-vs-fp64 spread is NOT part of the noise (USE_F64_SPREAD = False: it made the gradient
+              bounds 10-500x wider than the device needs -- the device repeats the oracle's float operations, only its
+              libm differs).
 
 so an ill-conditioned element can no longer excuse a well-conditioned one (the round-2 rule compared tensor-wide
-maxima and percentiles).  K = 4.
+maxima and percentiles).
 
 The reference's own skip thresholds get a term of their own.  A pair contributes iff D > 1e-6 (kernel.cu:784) and
 d^2 < dist_eps * tau (:769); a fragment that sits within a few ulps of a threshold flips with the last bit of expf /
 erfcf (device libm vs glibc), and with softmax RGB one such fragment alone sets the pixel's colour.  The oracle is
-therefore evaluated twice more in fp32 with both thresholds moved by -10 % / +10 % (`threshold_scale`; gumbel_min's
-1 - exp(-e^u) is quantised in steps of 6 % at D = 1e-6), and the bound of an element becomes
+therefore evaluated twice more in fp32 with the PROBABILITY threshold moved by -10 % / +10 % (gumbel_min's
+1 - exp(-e^u) is quantised in steps of 6 % at D = 1e-6) and dist_eps by -0.1 % / +0.1 % (`parity.run_oracle`,
+threshold_scale: a distance threshold flips by rounding only, a few ulps), and
 
-    max( 1e-5 * scale_e ,  K * noise_e ,  2 * flip_e ),   flip_e = max(|o32(0.9) - o32|, |o32(1.1) - o32|)
+    flip_e = max(|o32(0.9) - o32|, |o32(1.1) - o32|)
 
 taken over the pixel's channels resp. the face's components: what the pairs inside the band can move the element by
 (the factor 2: a subset of flips with mixed signs).  It is magnitude-aware -- a threshold fragment with D = 1e-6 moves a
-gradient by 1e-6 of its neighbours' contributions, so gradients stay held to 1e-5 almost everywhere.  The fraction
-of elements whose bound is wider than 1e-5 * scale is reported per tensor (`loosened`), split by cause.
+gradient by 1e-6 of its neighbours' contributions, so gradients stay held to 1e-5 almost everywhere.
+
+The share of elements whose bound is wider than 1e-5 * scale is reported per tensor (`loosened`, split by cause) and
+CAPPED: tests/golden/loosened_table.json holds, per (case, tensor), the share the rule loosens today (a property of the
+oracle alone -- computed on the CPU by tests/golden/make_loosened_table.py); `loosened_failures` rejects a report whose
+share exceeds the tabulated one (+ 2 points), so the rule cannot be widened silently.
 """
+import json
+import os
+
 import numpy as np
 
 import parity
@@ -164,11 +178,39 @@ def failures(report):
     return bad
 
 
-def check_case(fv, tex, image_size, opts, hip, grad, oracle_f32=None, n_jitter=len(JITTER_MODES)):
-    """-> (failure strings, report, references)."""
+LOOSENED_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loosened_table.json')
+LOOSENED_SLACK = 0.02
+_loosened = None
+
+
+def loosened_table():
+    global _loosened
+    if _loosened is None:
+        try:
+            with open(LOOSENED_TABLE) as f:
+                _loosened = json.load(f)['cases']
+        except (OSError, ValueError, KeyError):
+            _loosened = {}
+    return _loosened
+
+
+def loosened_failures(key, report):
+    """The share of elements NOT held to 1e-5 must not exceed what tests/golden/loosened_table.json records for the case
+    (absent: 0) by more than LOOSENED_SLACK."""
+    row = loosened_table().get(key, {})
+    return ['%s %s: %.1f %% of the elements are not held to 1e-5, the table allows %.1f %% (+ %.0f points)'
+            % (key, k, 100 * r['loosened'], 100 * row.get(k, 0.0), 100 * LOOSENED_SLACK)
+            for k, r in report.items() if r['loosened'] > row.get(k, 0.0) + LOOSENED_SLACK]
+
+
+def check_case(fv, tex, image_size, opts, hip, grad, oracle_f32=None, n_jitter=len(JITTER_MODES), key=None):
+    """-> (failure strings, report, references).  `key`: the case's name in the loosened table (None: no ceiling check)."""
     refs = references(fv, tex, image_size, opts, grad, oracle_f32, n_jitter)
     rep = elementwise(hip, refs)
-    return failures(rep), rep, refs
+    bad = failures(rep)
+    if key is not None:
+        bad += loosened_failures(key, rep)
+    return bad, rep, refs
 
 
 # cases whose forward is purely algebraic (no libm call before alpha): alpha must be bit-exact

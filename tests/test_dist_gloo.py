@@ -36,6 +36,14 @@ def _worker(rank, world, port, out):
         raise AssertionError('uneven blocks were accepted')
     except ValueError:
         pass
+    # ... also when one rank's block size is one it has gathered before (a per-rank cache of agreed sizes sent
+    # rank 0 straight into the all-gather while rank 1 issued the check's all-reduce -- both ranks timed out)
+    gather_views(torch.zeros(4, 2))
+    try:
+        gather_views(torch.zeros(4 - rank, 2))
+        raise AssertionError('a ragged step after an even one was accepted')
+    except ValueError:
+        pass
     # the incoming gradient buffer is not reduced in place
     x = torch.ones(2, 2, requires_grad=True)
     upstream = torch.ones(4, 2)

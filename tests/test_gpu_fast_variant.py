@@ -1,0 +1,87 @@
+"""The `fast` build variant (libgendr_hip_fast.so: -DGENDR_FAST_MATH=1 -ffp-contract=fast, gendr_amd/build.py) -- the
+reference's formulas, operation order, skip tests and culling with the per-pair arithmetic at hardware accuracy (float
+reciprocals, v_sqrt_f32, 2^x-based exp, contraction on) instead of the reference's rounding operation by operation.
+
+What "matches the reference" can mean for such a build: the reference's own kernels, compiled for this GPU
+twice (oracle/_ref: `render` without contraction -- the pin -- and `render_fma` with the compiler's default), differ from
+EACH OTHER far beyond 1e-5: the closest-point formula of kernel.cu:91-99 / :146-150 cancels catastrophically, so one
+different rounding moves isolated pixels by O(1) (BASELINE config 2: 4 % of the rgba elements of the two reference builds
+are more than 1e-5 apart, p99 1e-4, maximum 4.8 relative) -- and WHICH pixels are hit differs from one perturbation to the
+next, so an element-wise bracket by the two builds' difference cannot hold (measured: 0.2 % of C2's elements outside).  The
+tests hold what can be held:
+
+  * the variant is a rasterizer: culled == all-pairs bit for bit, finite where the default build is finite;
+  * on BASELINE's configurations and on the well-conditioned sphere scene its error DISTRIBUTION against the pin build stays
+    within SPREAD_K x the distribution of the reference's own spread, quantile by quantile (tests/pin.py spread_failures);
+    the option sets that leave it are enumerated in the committed table (`fast_outside_spread`), the set must not grow;
+The element-wise bracket counts are reported in profiles/parity_r04.json (tests/gpu_report.py), not asserted."""
+import os
+
+import numpy as np
+import pytest
+
+import parity
+import pin
+
+pytestmark = pytest.mark.gpu
+
+TABLE = pin.load_table()
+MATRIX = pin.MATRIX
+IDS = [n for n, _ in MATRIX]
+
+
+@pytest.fixture(scope='module')
+def fast_lib(native_lib):
+    from gendr_amd import build
+    if not os.path.exists(build.lib_path('fast')):
+        pytest.fail('libgendr_hip_fast.so is not built (gendr_amd.build.build_all())')
+
+
+@pytest.fixture(scope='module')
+def ref_kernels():
+    if not parity.reference_available():
+        pytest.skip('oracle/_ref is not built (python -m oracle.build_ref needs /root/reference)')
+
+
+@pytest.mark.parametrize("scene", pin.SCENES)
+@pytest.mark.parametrize("name,opts", MATRIX, ids=IDS)
+def test_fast_variant_culling_is_exact(fast_lib, name, opts, scene):
+    """Culling removes only pairs that contribute exactly nothing -- also under this variant's arithmetic (the cull boxes'
+    error bound carries a factor of two over the reference's roundings; contraction and 1-ulp quotients stay inside it)."""
+    isz = pin.MATRIX_SIZE
+    fv, tex = pin.matrix_inputs(opts, scene)
+    grad = pin.matrix_grad(fv, isz)
+    a = parity.run_hip(fv, tex, isz, opts, grad, variant='fast')
+    b = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad, variant='fast')
+    assert np.array_equal(a['rgba'], b['rgba'], equal_nan=True) and np.array_equal(a['aggrs_info'], b['aggrs_info'], equal_nan=True)
+    d = parity.run_hip(fv, tex, isz, opts, grad, variant='default')
+    for k in ('rgba', 'aggrs_info', 'grad_faces', 'grad_textures'):
+        assert not (np.isfinite(d[k]) & ~np.isfinite(a[k])).any(), (k, 'the fast variant is not finite where the default build is')
+
+
+def _spread_case(key, fv, tex, isz, opts, grad):
+    r = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
+    rf = parity.run_reference(fv, tex, isz, opts, grad, np.float32, variant='render_fma')
+    o = parity.run_oracle(fv, tex, isz, opts, grad, np.float32)
+    h = parity.run_hip(fv, tex, isz, opts, grad, variant='fast')
+    spread = pin.measure(rf, r, o['abs_faces'], o['abs_textures'])
+    m = pin.measure(h, r, o['abs_faces'], o['abs_textures'])
+    return m, spread, pin.spread_failures(key, m, spread)
+
+
+@pytest.mark.parametrize("name,opts,isz", pin.FULL, ids=[n for n, _, _ in pin.FULL])
+def test_fast_variant_inside_the_reference_spread_at_baseline_configs(oracle_mod, fast_lib, ref_kernels, name, opts, isz):
+    fv, tex = pin.full_inputs(name)
+    m, spread, bad = _spread_case(name, fv, tex, isz, opts, pin.full_grad(isz))
+    assert not bad, (bad, m, spread)
+
+
+@pytest.mark.parametrize("name,opts", MATRIX, ids=IDS)
+def test_fast_variant_inside_the_reference_spread_on_the_sphere(oracle_mod, fast_lib, ref_kernels, name, opts):
+    assert TABLE is not None, 'tests/golden/reference/pin_table.json is missing (tests/golden/make_pin_table.py)'
+    key = pin.case_key('sphere', name)
+    fv, tex = pin.matrix_inputs(opts, 'sphere')
+    m, spread, bad = _spread_case(key, fv, tex, pin.MATRIX_SIZE, opts, pin.matrix_grad(fv, pin.MATRIX_SIZE))
+    if key in TABLE.get('fast_outside_spread', {}):
+        pytest.xfail('tabulated: %s' % TABLE['fast_outside_spread'][key][:1])
+    assert not bad, (bad, m, spread)

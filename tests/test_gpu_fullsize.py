@@ -34,7 +34,7 @@ def test_one_full_frame_against_oracle(oracle_mod, native_lib, opts):
         assert res['rgba']['max_rel'] <= 1e-5
         assert res['grad_faces_cond']['max_rel'] <= 1e-5 and res['grad_textures_cond']['max_rel'] <= 1e-5
     grad = np.random.RandomState(1).randn(1, 4, 256, 256).astype(np.float32)
-    bad, _, _ = criteria.check_case(fv, tex, 256, opts, h, grad, oracle_f32=r)
+    bad, _, _ = criteria.check_case(fv, tex, 256, opts, h, grad, oracle_f32=r, key='C2' if opts is C2 else 'C3')
     assert not bad, bad
 
 
@@ -46,7 +46,7 @@ def test_large_frames_against_oracle(oracle_mod, native_lib, name, opts, isz):
     fv, tex = fv[1:2], tex[1:2]
     res, h, r = parity.compare(fv, tex, isz, opts)
     grad = np.random.RandomState(1).randn(1, 4, isz, isz).astype(np.float32)
-    bad, _, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r, n_jitter=6)
+    bad, _, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r, n_jitter=6, key=name)
     assert not bad, bad
 
 

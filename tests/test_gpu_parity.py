@@ -33,7 +33,7 @@ def test_option_matrix(oracle_mod, native_lib, scene, name, opts):
     fv, tex, isz = _scene(scene, opts)
     res, h, r = parity.compare(fv, tex, isz, opts)
     grad = np.random.RandomState(1).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
-    bad, rep, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r)      # element-wise rule
+    bad, rep, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r, key='%s:%s' % (scene, name))      # element-wise rule + the cap on its loosened share
     assert not bad, (scene, name, bad)
     if criteria.alpha_is_algebraic(name):
         assert np.array_equal(h['rgba'][:, 3], r['rgba'][:, 3]), 'alpha must be bit-exact on algebraic paths'

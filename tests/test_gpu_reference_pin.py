@@ -8,20 +8,21 @@ travels to the GPU box as a built artefact.  oracle/ref_gpu.py launches its kern
   * float64: the restatement (oracle/gendr_oracle_body.inc, S = double) has to reproduce the reference kernels'
     double instantiation to rounding noise on the whole option matrix -- libm differences are 1e-16 there, so a
     misread formula, promotion, threshold or traversal order shows at full size;
-  * float32: the restatement and the HIP product are both held to the reference kernels' float results by the same
-    element-wise rule the product is held to against the restatement (tests/criteria.py), and the face preprocessing
-    (kernel.cu:620) bit for bit.
+  * float32: the HIP product is held to the reference kernels' float results by a FLAT 1e-5 on every element of every
+    tensor, with an enumerated exception table (tests/pin.py, tests/golden/reference/pin_table.json); the restatement (a
+    different libm) by the element-wise rule of tests/criteria.py; the face preprocessing (kernel.cu:620) bit for bit.
 """
 import numpy as np
 import pytest
 
 import criteria
 import parity
+import pin
 import scenes
 
 pytestmark = pytest.mark.gpu
 
-MATRIX = [(n, o) for n, o in scenes.OPTION_MATRIX if o.get('texel_mode', 0) == 0]
+MATRIX = pin.MATRIX
 IDS = [n for n, _ in MATRIX]
 
 
@@ -71,56 +72,71 @@ def test_restatement_reproduces_reference_kernels_f64(oracle_mod, ref_kernels, n
         assert e.max() <= max(tol, 1e-8), (k, float(e.max()), np.unravel_index(int(e.argmax()), e.shape))
 
 
-def _against_reference(fv, tex, isz, opts, got, grad, ref_out, n_jitter):
-    """`got` (restatement or product, float) against the reference kernels' float output under the element-wise rule:
-    the noise and threshold terms come from the restatement's jittered / shifted evaluations, the value compared with is
-    the reference's."""
-    refs = criteria.references(fv, tex, isz, opts, grad, n_jitter=n_jitter)
-    pinned = dict(refs, o32=dict(ref_out, abs_faces=refs['o32']['abs_faces'], abs_textures=refs['o32']['abs_textures'],
-                                 grad_faces=ref_out['grad_faces'].reshape(refs['o32']['grad_faces'].shape)))
-    return criteria.failures(criteria.elementwise(got, pinned)), refs
+TABLE = pin.load_table()
 
 
-@pytest.mark.parametrize("scene", ['soup', 'sphere', 'slivers'])
+def _flat(key, got, ref, o):
+    """The flat 1e-5 gate against the reference kernels' float output (tests/pin.py): every tensor, every element, except
+    the (case, tensor) pairs of the committed exception table, which are held to twice their measured deviation."""
+    return pin.flat_failures(key, pin.measure(got, ref, o['abs_faces'], o['abs_textures']), TABLE)
+
+
+@pytest.mark.parametrize("scene", pin.SCENES)
 @pytest.mark.parametrize("name,opts", MATRIX, ids=IDS)
-def test_restatement_and_product_against_reference_kernels_f32(oracle_mod, native_lib, ref_kernels, name, opts, scene):
-    isz = 32
-    fv, tex = _inputs(opts, scene)
-    grad = _grad(fv, isz, np.float32)
+def test_product_against_reference_kernels_f32(oracle_mod, native_lib, ref_kernels, name, opts, scene):
+    """The HIP product against the reference's own kernels, float32: FLAT 1e-5 on rgba, aggrs_info and both gradients
+    (gradients relative to the sum of |contributions|: their summation order differs by design), bit for bit on the face
+    preprocessing and on alpha where no libm call is involved.  No noise term: the nine cases that miss 1e-5 -- gamma /
+    gaussian option sets whose last-bit libm differences the reference's own cancellation amplifies -- are enumerated in
+    tests/golden/reference/pin_table.json with what was measured (make the default gate mean 1e-5 where 1e-5 is
+    met)."""
+    assert TABLE is not None, 'tests/golden/reference/pin_table.json is missing (tests/golden/make_pin_table.py)'
+    isz = pin.MATRIX_SIZE
+    fv, tex = pin.matrix_inputs(opts, scene)
+    grad = pin.matrix_grad(fv, isz)
     r = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
     c = parity.run_oracle(fv, tex, isz, opts, grad, np.float32)
     assert np.array_equal(r['faces_info'], c['faces_info'], equal_nan=True)
     if criteria.alpha_is_algebraic(name):
         assert np.array_equal(r['rgba'][:, 3], c['rgba'][:, 3], equal_nan=True), 'alpha without a libm call must agree bit for bit'
-    bad, _ = _against_reference(fv, tex, isz, opts, c, grad, r, len(criteria.JITTER_MODES))
-    assert not bad, ('restatement vs reference kernels', bad)
     h = parity.run_hip(fv, tex, isz, opts, grad)
     if criteria.alpha_is_algebraic(name):
         assert np.array_equal(h['rgba'][:, 3], r['rgba'][:, 3], equal_nan=True)
-    bad, _ = _against_reference(fv, tex, isz, opts, h, grad, r, len(criteria.JITTER_MODES))
+    bad = _flat(pin.case_key(scene, name), h, r, c)
     assert not bad, ('HIP product vs reference kernels', bad)
 
 
-C2 = dict(dist_func='uniform', dist_scale=1e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax', double_side=False)
-C3 = dict(dist_func='gaussian', dist_scale=1e-4, dist_squared=True, aggr_alpha_func='einstein', double_side=False)
-C4 = dict(dist_func='logistic', dist_scale=1e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax', double_side=False)
-C5 = dict(dist_func='gamma', dist_shape=2.0, dist_scale=1e-2, aggr_alpha_func='yager', aggr_alpha_t_conorm_p=2.0,
-          aggr_rgb_func='softmax', texture_type='vertex', double_side=False)
+@pytest.mark.parametrize("scene", pin.SCENES)
+@pytest.mark.parametrize("name,opts", MATRIX, ids=IDS)
+def test_restatement_against_reference_kernels_f32(oracle_mod, ref_kernels, name, opts, scene):
+    """The CPU restatement (glibc) against the reference kernels (the GPU's libm), float32: the element-wise rule of
+    tests/criteria.py -- two different libms need its noise term -- with the reference kernels' output as the value
+    compared with."""
+    isz = pin.MATRIX_SIZE
+    fv, tex = pin.matrix_inputs(opts, scene)
+    grad = pin.matrix_grad(fv, isz)
+    r = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
+    refs = criteria.references(fv, tex, isz, opts, grad)
+    c = refs['o32']
+    pinned = dict(refs, o32=dict(r, abs_faces=c['abs_faces'], abs_textures=c['abs_textures'], grad_faces=r['grad_faces'].reshape(c['grad_faces'].shape)))
+    bad = criteria.failures(criteria.elementwise(c, pinned))
+    assert not bad, ('restatement vs reference kernels', bad)
 
 
-@pytest.mark.parametrize("name,opts,isz", [('C2', C2, 256), ('C3', C3, 256), ('C4', C4, 512), ('C5', C5, 768)])
+@pytest.mark.parametrize("name,opts,isz", pin.FULL, ids=[n for n, _, _ in pin.FULL])
 def test_product_against_reference_kernels_at_baseline_configs(oracle_mod, native_lib, ref_kernels, name, opts, isz):
-    """BASELINE.json's configurations (C5's option set at 768^2), one frame of the benchmark mesh: the HIP product
-    against the reference kernels' float output; float64: the restatement against the reference kernels."""
-    from gendr_amd.synthetic import benchmark_scene
-    fv, tex = benchmark_scene(2, texture='vertex' if name == 'C5' else 'surface')
-    fv, tex = fv.numpy()[1:2], tex.numpy()[1:2]
-    grad = np.random.RandomState(1).randn(1, 4, isz, isz).astype(np.float32)
+    """BASELINE.json's configurations (C5's option set at 768^2), one frame of the benchmark mesh: the HIP product against
+    the reference kernels' float output under the flat gate (C2 and C4: 1e-5 everywhere, rgba bit for bit; C3 / C5: the
+    tabulated deviation of their face gradients); float64: the restatement against the reference kernels."""
+    assert TABLE is not None
+    fv, tex = pin.full_inputs(name)
+    grad = pin.full_grad(isz)
     r = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
     h = parity.run_hip(fv, tex, isz, opts, grad)
-    if name == 'C2':
-        assert np.array_equal(h['rgba'][:, 3], r['rgba'][:, 3])
-    bad, _ = _against_reference(fv, tex, isz, opts, h, grad, r, 6)
+    c = parity.run_oracle(fv, tex, isz, opts, grad, np.float32)
+    if name in ('C2', 'C4'):
+        assert np.array_equal(h['rgba'], r['rgba']) and np.array_equal(h['aggrs_info'], r['aggrs_info']), 'forward must be bit-identical to the reference kernels'
+    bad = _flat(name, h, r, c)
     assert not bad, bad
     r64 = parity.run_reference(fv, tex, isz, opts, grad, np.float64)
     c64 = parity.run_oracle(fv.astype(np.float64), tex.astype(np.float64), isz, opts, grad.astype(np.float64), np.float64)
@@ -129,6 +145,20 @@ def test_product_against_reference_kernels_at_baseline_configs(oracle_mod, nativ
         assert _rel(r64[k], c64[k]).max() <= 1e-9, k
     for k, ak in (('grad_faces', 'abs_faces'), ('grad_textures', 'abs_textures')):
         assert _rel(r64[k], c64[k], scale=c64[ak], floor=GRAD_FLOOR).max() <= 1e-8, k
+
+
+def test_injected_error_turns_the_gate_red(oracle_mod, native_lib, ref_kernels):
+    """A 1e-4 relative error on the face gradients must fail the gate on a clean case (C4: flat 1e-5) AND on a tabulated
+    one (C3: the share of elements above 1e-5 and the 99th percentile are held, not only the maximum)."""
+    for name, opts, isz in pin.FULL[1:3]:
+        fv, tex = pin.full_inputs(name)
+        grad = pin.full_grad(isz)
+        r = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
+        h = parity.run_hip(fv, tex, isz, opts, grad)
+        c = parity.run_oracle(fv, tex, isz, opts, grad, np.float32)
+        assert not _flat(name, h, r, c)
+        h['grad_faces'] = h['grad_faces'] * np.float32(1 + 1e-4)
+        assert _flat(name, h, r, c), name
 
 
 def test_reference_builds_differ_by_contraction(oracle_mod, ref_kernels):
@@ -141,3 +171,6 @@ def test_reference_builds_differ_by_contraction(oracle_mod, ref_kernels):
     d = _rel(b['rgba'], a['rgba'])
     print('reference, contraction on vs off: rgba max rel %.3g, differing elements %.2f %%' % (d.max(), 100 * (d > 0).mean()))
     assert np.isfinite(a['rgba']).all()
+    # the number every "within 1e-5 of the reference" statement has to be read against: the reference's own two builds are
+    # farther apart than that on a sizeable share of this scene's pixels
+    assert (d > 1e-5).mean() > 0.01
