@@ -7,12 +7,12 @@ otherwise.  A step = one forward and one backward of the autograd Function (`gen
 on inputs already resident in HBM.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), the batch axis is
-sharded and the data path has no collective.  Headline since round 3: WEAK scaling -- every GPU renders the
-config's batch (64 frames per GPU, 64 N in all), which is what the task contract prescribes for a path that
-partitions into independent units ("scaling": "weak").  The STRONG figure -- SURVEY 8(d): 64 frames in total,
-64 / N per GPU -- is measured in the same run and reported under "extra" -> "strong" (`--scaling strong` makes
-it the headline instead); on one GPU the two are the same measurement, and "extra" -> "strong_projection"
-carries what the single-GPU batch sweep predicts for it.
+sharded and the data path has no collective.  Headline (round 4, as up to round 2): STRONG scaling -- BASELINE.json's
+metric is "batch 64; 1/2/4/8 GPU" and SURVEY 8(d) says "batch sharded evenly": 64 frames in total, 64 / N per GPU.
+The WEAK figure (every GPU renders the config's batch: 64 N frames in all -- flat by construction, the data path has
+no collective) is measured in the same run and reported under "extra" -> "weak" (`--scaling weak` swaps the two); on
+one GPU the two are the same measurement, and "extra" -> "strong_projection" carries what the single-GPU batch sweep
+predicts for the strong figure.
 `python bench.py --gpus N` starts the N ranks itself when it is not already running under torchrun
 (WORLD_SIZE unset); under the driver's `python -m torch.distributed.run ... bench.py --gpus N` it reads
 RANK / LOCAL_RANK / WORLD_SIZE from the environment.
@@ -249,8 +249,9 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=None, help='GLOBAL batch (default: the config\'s)')
-    ap.add_argument('--scaling', default='weak', choices=('strong', 'weak'),
-                    help='weak (headline): the config\'s batch per GPU; strong: the config\'s batch in all, sharded (reported under extra otherwise)')
+    ap.add_argument('--scaling', default='strong', choices=('strong', 'weak'),
+                    help='strong (headline, SURVEY 8(d): "batch sharded evenly"): the config\'s batch in all, 1/N of it per GPU; weak: the '
+                         'config\'s batch per GPU (reported under extra otherwise)')
     ap.add_argument('--launch', default='auto', choices=('auto', 'eager', 'graph'),
                     help='graph: the step is captured once in a HIP graph and replayed (configs without a collective); '
                          'auto: graph when a rank holds at most 32 frames (the step is then about as short as the host\'s '
@@ -452,6 +453,151 @@ def measure(args, wl, dist, dev):
     return out
 
 
+
+# ------------------------------------------------------------------------------------------------------------
+# extras of the single-GPU line: the flagged fast build variant, eager vs replayed launches, and the
+# shapes the reference's own scripts render
+# ------------------------------------------------------------------------------------------------------------
+def fast_variant_extra(args, cfg, rank, world, dev, dist):
+    """The same measurement through libgendr_hip_fast.so (gendr_amd/build.py VARIANTS['fast']: the reference's formulas,
+    order, skip tests and culling with the per-pair arithmetic at hardware accuracy and contraction on).  Never the
+    headline: it does not reproduce the reference's rounding; its parity standing is quoted from the committed table."""
+    from gendr_amd import _native, build
+    if not os.path.exists(build.lib_path('fast')):
+        return {'error': 'libgendr_hip_fast.so is not built'}
+    with _native.use_variant('fast'):
+        wl = Workload(args, cfg, rank, world, dev, args.scaling)
+        a = argparse.Namespace(**dict(vars(args), steps=max(10, args.steps), warmup=3))
+        m = measure(a, wl, dist, dev)
+    out = {'value': wl.global_batch * a.steps / m['elapsed'], 'unit': 'frames/s', 'ms_per_step': m['elapsed'] / a.steps * 1e3,
+           'launch': m['launch'], 'steps': a.steps,
+           'kernel_ms': {'forward_phase': m['fwd_ms'], 'backward_phase': m['bwd_ms']},
+           'what': '-DGENDR_FAST_MATH=1 -ffp-contract=fast: float reciprocals (<= 1 ulp) instead of exactly rounded quotients, v_sqrt_f32, '
+                   '2^x-based exp, float instead of double sub-expressions, contraction on; formulas, operation order, skip tests and '
+                   'culling unchanged'}
+    try:
+        t = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference', 'pin_table.json')))
+        name = args.config.upper()
+        br = t.get('fast_bracket', {}).get(name, {})
+        out['parity'] = {
+            'gate': 'tests/test_gpu_fast_variant.py: culled == all-pairs bit for bit; error quantiles (p50..p99.9) against the reference\'s '
+                    'own kernels within 4x the same quantiles of the spread of the reference\'s two builds (contraction off / on)',
+            'inside_reference_spread': name not in t.get('fast_outside_spread', {}),
+            'elements_outside_elementwise_bracket': {k: '%d of %d' % (v['violations'], v['n']) for k, v in br.items()},
+            'deviation_from_reference_kernels': t.get('fast', {}).get(name),
+            'note': 'does NOT reproduce the reference\'s rounding (the default build does: rgba bit-identical to the reference\'s kernels at '
+                    'C2 / C4); the reference\'s own contracted build deviates from its uncontracted one as much as this variant does',
+            'table_kernel_sha': t.get('meta', {}).get('kernel_sha')}
+    except Exception as e:
+        out['parity'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
+
+
+def other_launch_extra(args, wl, dist, dev, used):
+    """The launch mode the headline did NOT use, measured on the same workload: the reference's callers are eager Python
+    loops, the headline usually replays a captured HIP graph."""
+    other = 'eager' if used == 'graph' else 'graph'
+    a = argparse.Namespace(**dict(vars(args), launch=other, steps=max(10, args.steps), warmup=3))
+    m = measure(a, wl, dist, dev)
+    return other, {'value': wl.global_batch * a.steps / m['elapsed'], 'unit': 'frames/s', 'ms_per_step': m['elapsed'] / a.steps * 1e3,
+                   'launch': m['launch'], 'steps': a.steps}
+
+
+def caller_shapes_extra(dev, steps=30):
+    """What the reference's own scripts render, through GenDR.forward, EAGER (they are Python loops), on the 1280-face
+    icosphere at 64^2:
+      opt_shape       experiments/opt_shape.py:134-159,289-303: 24 views; soft renderer (logistic, probabilistic, hard RGB,
+                      dist_eps 100, sigma 1e-2) forward + backward of the silhouette, then the hard renderer (dist_func 0,
+                      aggr_alpha_func 0, dist_eps 1) forward under no_grad
+      reconstruction  experiments/train_reconstruction.py:181-196,226-231,506,518,557: 4 x 64 = 256 views, uniform,
+                      tau = 10^-1.5, probabilistic, hard RGB, dist_eps 300, forward + backward of the silhouettes
+    ms per step with eager launches and with the same step replayed from a HIP graph; their ratio is the share of the eager
+    step the host (Python, autograd, 6-7 launches per render) accounts for."""
+    import torch
+    import gendr_amd
+    from gendr_amd.synthetic import benchmark_scene
+    out = {}
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    def both(step, params):
+        for _ in range(5):
+            step()
+        eager = min(timed(step, steps), timed(step, steps))
+        replay = None
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(s)
+            for p in params:
+                p.grad = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                step()
+            g.replay()
+            replay = min(timed(g.replay, steps), timed(g.replay, steps))
+        except Exception as e:
+            sys.stderr.write('bench: caller-shape graph capture failed (%s)\n' % (e,))
+        return eager, replay
+
+    class M(object):
+        pass
+
+    # opt_shape.py
+    fv, tex = benchmark_scene(24, device=dev)
+    fv.requires_grad_(True)
+    soft = gendr_amd.GenDR(image_size=64, dist_func='logistic', dist_scale=1e-2, dist_squared=False, dist_shape=0., dist_shift=0.,
+                           dist_eps=100, aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=0., aggr_rgb_func='hard')
+    hard = gendr_amd.GenDR(image_size=64, dist_func=0, dist_scale=1e-4, dist_squared=True, dist_shape=0., dist_shift=0., dist_eps=1,
+                           aggr_alpha_func=0, aggr_alpha_t_conorm_p=0., aggr_rgb_func='hard')
+    mesh = M()
+    mesh.face_vertices, mesh.face_textures = fv, tex
+    target = torch.rand(24, 64, 64, device=dev)
+
+    def step_opt():
+        fv.grad = None
+        sil = soft(mesh)[:, 3]
+        ((sil - target) ** 2).mean().backward()
+        with torch.no_grad():
+            hard(mesh)[:, 3]
+
+    e, r = both(step_opt, [fv])
+    out['opt_shape_64x64_b24_soft_fwd_bwd_plus_hard_fwd'] = {
+        'eager_ms_per_step': e, 'graph_replay_ms_per_step': r, 'frames_per_s_eager': 24 / e * 1e3,
+        'host_bound_share_of_eager_step': (None if r is None else max(0.0, 1.0 - r / e))}
+
+    # train_reconstruction.py
+    fv2, tex2 = benchmark_scene(256, device=dev)
+    fv2.requires_grad_(True)
+    rec = gendr_amd.GenDR(image_size=64, dist_func='uniform', dist_scale=10 ** -1.5, dist_squared=False, dist_shape=0, dist_shift=0,
+                          dist_eps=300., aggr_alpha_func='probabilistic', aggr_alpha_t_conorm_p=0, aggr_rgb_func='hard')
+    mesh2 = M()
+    mesh2.face_vertices, mesh2.face_textures = fv2, tex2
+    target2 = torch.rand(256, 64, 64, device=dev)
+
+    def step_rec():
+        fv2.grad = None
+        sil = rec(mesh2)[:, 3]
+        ((sil - target2) ** 2).mean().backward()
+
+    e, r = both(step_rec, [fv2])
+    out['train_reconstruction_64x64_b256_dist_eps_300_fwd_bwd'] = {
+        'eager_ms_per_step': e, 'graph_replay_ms_per_step': r, 'frames_per_s_eager': 256 / e * 1e3,
+        'host_bound_share_of_eager_step': (None if r is None else max(0.0, 1.0 - r / e))}
+    out['note'] = ('through gendr_amd.GenDR.forward with eager launches, as the reference\'s scripts run; the step includes the loss '
+                   '(two tensor ops) and autograd; graph_replay = the same step captured once and replayed: what the GPU alone needs')
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -592,7 +738,23 @@ def main():
                 del wl300
             except Exception as e:
                 extra['dist_eps_300'] = {'error': '%s: %s' % (type(e).__name__, e)}
-            sweep = os.path.join(ROOT, 'profiles', 'r03_%s_batch_sweep.json' % args.config)
+            try:
+                other, res = other_launch_extra(args, wl, dist, dev, m['launch'])
+                extra[other] = res
+            except Exception as e:
+                extra['other_launch'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            try:
+                extra['fast_variant'] = fast_variant_extra(args, cfg, rank, world, dev, dist)
+            except Exception as e:
+                extra['fast_variant'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            if args.config == 'c2':
+                try:
+                    extra['caller_shapes'] = caller_shapes_extra(dev)
+                except Exception as e:
+                    extra['caller_shapes'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            sweep = os.path.join(ROOT, 'profiles', 'r04_%s_batch_sweep.json' % args.config)
+            if not os.path.exists(sweep):
+                sweep = os.path.join(ROOT, 'profiles', 'r03_%s_batch_sweep.json' % args.config)
             if os.path.exists(sweep):
                 try:
                     from gendr_amd import build as _b
@@ -601,7 +763,7 @@ def main():
                         'speedup_at_n_gpus': sw['strong_projection'], 'ms_per_step_at_batch': sw['batches'],
                         'current_kernels': sw.get('kernel_sha') == _b.source_sha(),
                         'note': 'PROJECTION, not a measurement: t(batch 64) / t(batch 64 / N) of this op on ONE MI355X '
-                                '(profiles/r03_%s_batch_sweep.json, tools/batch_sweep.py); no multi-GPU run is behind it' % args.config}
+                                '(profiles/%s, tools/batch_sweep.py); no multi-GPU run is behind it' % os.path.basename(sweep)}
                 except Exception:
                     pass
             if extra:

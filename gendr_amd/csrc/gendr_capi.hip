@@ -123,6 +123,7 @@ extern "C" float gendr_cull_radius(const gendr_params* p);
 struct Workspace {
     size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, hints_off, sorted_off, loose_off, control_off, det_off, total;
     bool ordered;              // the render kernels walk the heavy-first copy of the queue records (order_tiles_kernel)
+    bool loose_lists;          // large images: flagged faces are boxed by loose_faces_kernel ahead of the binning kernel
     bool hints;                // the forward kernel leaves pair hints for the backward kernel (gendr_params::pair_hints)
     int tiles_x, chunks, supers_x, ncontrol;
     long ent_cap8;
@@ -195,9 +196,10 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     // where every tile could start at once, made batch 8 slower -- 123 vs 108 us per step -- since the sub-tile split puts
     // more work items than wave slots into the launch); no pool: no pair counts to order by
     w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16 && w.ent_cap8 > 0;
-    // faces with a loose cull box (loose_faces_kernel): [flag B*nf i32][box B*nf 4 x i32][list per image B x 16 i32]
+    // faces with a loose cull box, large images (loose_faces_kernel): [flag B*nf i32][box B*nf 4 x i32][list per image B x 16 i32]
     w.loose_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
-    w.control_off = w.loose_off + align256((size_t)B * nf * sizeof(int)) + align256((size_t)B * nf * sizeof(int4)) + align256((size_t)B * kLooseList * sizeof(int));
+    w.loose_lists = (long)w.tiles_x * w.tiles_x >= GENDR_LOOSE_MIN_TILES;
+    w.control_off = w.loose_off + (w.loose_lists ? align256((size_t)B * nf * sizeof(int)) + align256((size_t)B * nf * sizeof(int4)) + align256((size_t)B * kLooseList * sizeof(int)) : 0);
     w.ncontrol = kCtlInts;
     // deterministic backward: [count + list of the deferred faces][their band sums]
     w.det_off = w.control_off + align256((size_t)w.ncontrol * sizeof(int));
@@ -247,11 +249,13 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.tile_info = w.ordered ? reinterpret_cast<int4*>(static_cast<char*>(const_cast<void*>(workspace)) + w.sorted_off) : a.tile_info_raw;
     a.entries = reinterpret_cast<CoverEnt*>(static_cast<char*>(const_cast<void*>(workspace)) + w.entries_off);
     a.ent_cap8 = w.ent_cap8;
-    {
+    if (w.loose_lists) {
         char* lb = static_cast<char*>(const_cast<void*>(workspace)) + w.loose_off;
         a.loose_flag = reinterpret_cast<const int*>(lb);
         a.loose_box = reinterpret_cast<int4*>(lb + align256((size_t)B * nf * sizeof(int)));
         a.loose_image = reinterpret_cast<int*>(lb + align256((size_t)B * nf * sizeof(int)) + align256((size_t)B * nf * sizeof(int4)));
+    }
+    {
         const float r = gendr_cull_radius(p);
         // (radius (1 + 2^-10))^2 rounded up: a computed squared distance that reaches it lies beyond the radius
         a.cull_r2 = r < 1e18f ? nextafterf((float)((double)r * (double)r * (1. + 1. / 512.)), INFINITY) : INFINITY;
@@ -266,6 +270,7 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.total_tiles = a.tiles_per_image * B;
     a.total_blocks = (a.total_tiles + (kThreads / 64) - 1) / (kThreads / 64);
     a.chunks = w.chunks;
+    a.rec_floats = record_floats(texm);
     a.p = *p;
     a.thr = p->dist_eps * p->dist_scale;                         // float * float, kernel.cu:725
     a.softmax_sum0 = expf(p->aggr_rgb_eps / p->aggr_rgb_gamma);  // kernel.cu:729
@@ -670,29 +675,29 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     const float cull_r = gendr_cull_radius(p);
     RenderArgs a;
     fill_args(a, workspace, textures, B, nf, T, p);
-    // faces with a loose cull box (face_setup_kernel flags them, loose_faces_kernel finds their live pixels): only with a finite
-    // cull radius.  The per-image lists start with a tag word; the binning kernel clears it after use, so a workspace that is
-    // used again -- also by the replay of a captured HIP graph, whose kernel arguments never change -- starts from empty lists,
-    // and fresh memory holds the tag only by a 2^-27 chance (the kernel then ignores face numbers out of range).
-    // ... and only for images of at least GENDR_LOOSE_MIN_TILES tiles (1024^2): the extra launch costs 10 us when an image has
-    // such a face and 5 us when none has, which at 256^2 is what it saves (C2: forward -5, backward -3, coverage -3 us against
-    // +10; a small batch pays without gaining), while at 2048^2 one such face is listed in 65 536 tiles (C5: +8 %).
-    const bool loose_on = GENDR_LOOSE_FACES && cull_r < INFINITY && total > 0 && p->cull && p->loose_faces >= 0 &&
-                          (p->loose_faces > 0 || (long)a.tiles_per_image >= GENDR_LOOSE_MIN_TILES);
-    if (!loose_on) a.loose_flag = nullptr;
+    // Faces with a loose cull box: face_setup_kernel flags them in their record and the coverage kernel evaluates them on the
+    // pixels of every tile they are listed in (only with a finite cull radius and an entry pool: no pool, no coverage kernel).
+    // In images of GENDR_LOOSE_MIN_TILES tiles and more (1024^2) -- where such a face is listed in tens of thousands of tiles
+    // -- loose_faces_kernel first evaluates it on every pixel once (one more launch: 10 us when an image has such a face, 5 us
+    // when none has) and the binning kernel lists it by the bounding box of its live pixels.  The per-image lists of that
+    // path start with a tag word; the binning kernel clears it after use, so a workspace that is used again -- also by the
+    // replay of a captured HIP graph, whose kernel arguments never change -- starts from empty lists, and fresh memory holds the
+    // tag only by a 2^-27 chance (the kernel then ignores face numbers out of range).
+    const int loose_on = (GENDR_LOOSE_FACES && cull_r < INFINITY && total > 0 && p->cull && p->loose_faces >= 0 && w.ent_cap8 > 0) ? 1 : 0;
+    if (!loose_on || !w.loose_lists) a.loose_flag = nullptr;
     a.loose_stamp = 0x05a17c3d;                                                  // 27 bits: the list heads hold tag << 4 | entries
     if (texm == kTexSurface1)
         hipLaunchKernelGGL(face_setup_kernel<kTexSurface1>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L,
-                           const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
+                           loose_on, const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
     else if (texm == kTexVertex)
         hipLaunchKernelGGL(face_setup_kernel<kTexVertex>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L,
-                           const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
+                           loose_on, const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
     else
         hipLaunchKernelGGL(face_setup_kernel<kTexSurfaceN>, dim3(blocks), dim3(64), 0, s, faces, textures, boxes, recs, total, sthr, cull_r, control, w.ncontrol, p->near_, p->far_, (float4*)nullptr, 0L,
-                           const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
+                           loose_on, const_cast<int*>(a.loose_flag), a.loose_box, a.loose_image, a.loose_stamp, nf);
     int e = check_launch();
     if (e != GENDR_OK) return e;
-    if (loose_on) {
+    if (a.loose_flag) {
         if (texm == kTexSurface1)    hipLaunchKernelGGL(loose_faces_kernel<record_floats(kTexSurface1)>, dim3(kLooseWaves), dim3(kThreads), 0, s, a);
         else if (texm == kTexVertex) hipLaunchKernelGGL(loose_faces_kernel<record_floats(kTexVertex)>, dim3(kLooseWaves), dim3(kThreads), 0, s, a);
         else                         hipLaunchKernelGGL(loose_faces_kernel<record_floats(kTexSurfaceN)>, dim3(kLooseWaves), dim3(kThreads), 0, s, a);

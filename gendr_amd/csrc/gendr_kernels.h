@@ -28,8 +28,9 @@
 //   * pair hints (round 3): the forward kernel leaves two bits per evaluated pair -- the edge its closest-point search
 //     selected, or "no gradient" -- and the backward kernel evaluates that one edge instead of searching again (same
 //     operations for that edge: bit-identical values), skipping batches and tiles that hold no live pair;
-//   * a face whose cull box is loose (seen edge-on: no error bound) is evaluated once on every pixel of its image
-//     (loose_faces_kernel, images of 1024^2 and more) and binned by the box of the pixels that can contribute;
+//   * a face whose cull box is loose (seen edge-on: no error bound) is evaluated by the coverage kernel on the pixels of every
+//     tile it is listed in and keeps exactly the pixels that can contribute; in images of 1024^2 and more loose_faces_kernel
+//     first evaluates it on every pixel once and the binning kernel lists it by the box of the pixels that can contribute;
 //   * everything is wave-local: no workgroup barriers in the render kernels, one wave-tile per workgroup.
 //
 // No MFMA: there is no dense contraction in this path.  Compiled with -ffp-contract=off.
@@ -100,7 +101,7 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 #define GENDR_LOOSE_AREA 1.0f    // visible NDC area of a cull box from which face_setup_kernel calls it loose (the image has 4)
 #endif
 #ifndef GENDR_LOOSE_MIN_TILES
-#define GENDR_LOOSE_MIN_TILES 16384
+#define GENDR_LOOSE_MIN_TILES 16384   // tiles per image from which loose_faces_kernel narrows the boxes of flagged faces ahead of the binning kernel
 #endif
 #ifndef GENDR_LOOSE_FACES
 #define GENDR_LOOSE_FACES 1    // 0: faces without a usable error bound keep the reference's cull box (A/B builds)
@@ -193,7 +194,7 @@ constexpr int kRecRZ    = 42;   // 3 doubles: 1 / z_k   (:809, :1027-1029)
 constexpr int kRecTex   = 48;   // TEXM 0: own rgb, next-face rgb ; TEXM 1: 3 vertex colours ; TEXM 2: nothing
 constexpr int kLooseList = 16;         // ints per image in RenderArgs::loose_image: stamped counter + up to 15 flagged faces
 constexpr int kLooseWaves = 2048;      // grid of loose_faces_kernel (one-wave workgroups)
-constexpr int kRecLoose = 17;  // int bits: 1 = the cull box is loose (no usable error bound); bin / cover kernels then take the box of loose_faces_kernel
+constexpr int kRecLoose = 17;  // int bits: 1 = the cull box is loose (no usable error bound): the coverage kernel finds the face's pixels by evaluation
 constexpr int kRecStage1 = 20, kRecStage3 = 42;
 constexpr int kBitFront = 8;      // record flag bits next to the obtuse-corner bits 1, 2, 4
 constexpr int kBitDepthSafe = 16; // all three vertex depths well inside [near, far]: the clipped depth cannot fail :810 / :994
@@ -249,6 +250,9 @@ constexpr int kHintDead = 3;
 // tiles) and 2 (some pair of the queue cannot be described by a hint -- the inside branch selected no edge, kHintNone, which
 // takes NaN or infinite candidates on a degenerate face -- backward then repeats the whole search for that queue)
 constexpr int kCtlHintFlag = 1;
+// control[x * kCtlStride + kCtlLive]: (order_tiles_kernel) the tiles of queue x with a non-empty coverage list; they come first
+// in the heavy-first copy of the queue records
+constexpr int kCtlLive = 2;
 
 __device__ __forceinline__ long queue_begin(int x, long n_tiles) { return ((long)x * n_tiles) >> 3; }
 // the x with queue_begin(x) <= g < queue_begin(x + 1)
@@ -284,12 +288,14 @@ struct RenderArgs {
     int*   det_list;
     float* det_partial;
     int resident_q;             // waves of the launched render kernel the chip holds at once, per tile queue (sub-tile split)
-    // faces whose cull box is loose (see loose_faces_kernel): per face a flag and the box of its live pixels (columns
-    // lo / hi, rows lo / hi; empty: lo > hi), per image a list of kLooseList ints: (loose_stamp << 4 | entries), then the faces
+    // faces whose cull box is loose, images of kLooseMinTiles tiles and more (see loose_faces_kernel): per face a flag and the
+    // box of its live pixels (columns lo / hi, rows lo / hi; empty: lo > hi), per image a list of kLooseList ints:
+    // (loose_stamp << 4 | entries), then the faces.  NULL: no lists (smaller images: the coverage kernel alone deals with them)
     const int*  loose_flag;
     int4*       loose_box;
     int*        loose_image;
     int         loose_stamp;
+    int         rec_floats;     // floats per face record (record_floats(texture mode)): for the kernels that are not templated on it
     float       cull_r2;        // (cull radius)^2, rounded up: an outside pixel whose computed squared distance reaches it is dead
     gendr_params p;
     float thr;                  // dist_eps * dist_scale (kernel.cu:725)
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     float* __restrict__ boxes, float* __restrict__ records,
     long total_faces, float sthr, float cull_r, int* __restrict__ control, int ncontrol, float near_, float far_,
     float4* __restrict__ clear4, long clear_quads,
-    int* __restrict__ loose_flag, int4* __restrict__ loose_box, int* __restrict__ loose_image, int loose_stamp, int nf)
+    int flag_loose, int* __restrict__ loose_flag, int4* __restrict__ loose_box, int* __restrict__ loose_image, int loose_stamp, int nf)
 {
     constexpr int REC = record_floats(TEXM);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // launched with one wavefront per workgroup
@@ -484,33 +490,36 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     }
 
     // A LOOSE cull box: the error bound E dwarfs the cull radius (determinant clamped or tiny: the face is seen edge-on), so
-    // the box is the reference's own margin or close to it -- the whole image at the default dist_eps -- and the face would be
-    // listed, with every pixel, in every tile of its image, although next to none of those pairs passes the skip tests.
-    // Such faces (rare; three of the 64 benchmark views hold two each) are flagged here, loose_faces_kernel then evaluates
-    // them on every pixel of their image ONCE, with the render kernels' own pair functions, and leaves the bounding box of the
-    // pixels that can contribute at all; the binning and coverage kernels use that box for them.
+    // the box is the reference's own margin or close to it -- the whole image at the default dist_eps -- and the face is listed
+    // in every tile of its image, although next to none of those pairs passes the skip tests.  Such faces (rare; three of the 64
+    // benchmark views hold two each) are flagged in their record; the coverage kernel then EVALUATES them on the pixels of
+    // every tile, with the render kernels' own pair functions, and keeps exactly the pixels that can contribute.
     bool loose = false;
-    if (in_range && cull_r < INFINITY && loose_flag) {
+    if (in_range && cull_r < INFINITY && flag_loose) {
         const float bw = fminf(xhi, 1.f) - fmaxf(xlo, -1.f), bh = fminf(yhi, 1.f) - fmaxf(ylo, -1.f);         // visible part of the box
         const float fw = fmaxf(fminf(xmax, 1.f) - fmaxf(xmin, -1.f), 0.f) + 4.f * cull_r, fh = fmaxf(fminf(ymax, 1.f) - fmaxf(ymin, -1.f), 0.f) + 4.f * cull_r;
         loose = bw > 0.f && bh > 0.f && bw * bh >= GENDR_LOOSE_AREA && bw * bh > 4.f * fw * fh;     // a good part of the image (NDC area 4), four times what the face itself explains
-        loose_flag[i] = loose ? 1 : 0;
-        if (loose) {
-            // append to the image's list: [0] = (tag << 4 | entries), [1 ..] the faces.  The tag tells a list head from whatever
-            // fresh memory holds; the binning kernel empties the list after use.  A full list leaves the face its whole image
-            // (the state before round 3).
-            int* list = loose_image + (i / nf) * kLooseList;
-            int slot = -1;
-            for (int cur = __hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);;) {
-                const int have = (cur >> 4) == loose_stamp ? (cur & 15) : 0;
-                if (have >= kLooseList - 1) break;
-                const int want = (loose_stamp << 4) | (have + 1);
-                const int seen = atomicCAS(list, cur, want);
-                if (seen == cur) { slot = have; break; }
-                cur = seen;
+        if (loose_flag) {
+            // Large images (kLooseMinTiles tiles and more: a flagged face is listed in all 65 536 tiles of a 2048^2 image): the face
+            // also goes on a short list of its image, loose_faces_kernel evaluates the listed faces on every pixel ONCE and leaves
+            // the bounding box of the live ones, and the binning kernel lists the face by that box.
+            loose_flag[i] = loose ? 1 : 0;
+            if (loose) {
+                // append to the image's list: [0] = (tag << 4 | entries), [1 ..] the faces.  The tag tells a list head from whatever
+                // fresh memory holds; the binning kernel empties the list after use.  A full list leaves the face its whole image.
+                int* list = loose_image + (i / nf) * kLooseList;
+                int slot = -1;
+                for (int cur = __hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);;) {
+                    const int have = (cur >> 4) == loose_stamp ? (cur & 15) : 0;
+                    if (have >= kLooseList - 1) break;
+                    const int want = (loose_stamp << 4) | (have + 1);
+                    const int seen = atomicCAS(list, cur, want);
+                    if (seen == cur) { slot = have; break; }
+                    cur = seen;
+                }
+                if (slot >= 0) { list[1 + slot] = (int)(i % nf); loose_box[i] = make_int4(0x7fffffff, -1, 0x7fffffff, -1); }
+                else           loose_box[i] = make_int4(0, 0x7ffffff0, 0, 0x7ffffff0);       // every pixel
             }
-            if (slot >= 0) { list[1 + slot] = (int)(i % nf); loose_box[i] = make_int4(0x7fffffff, -1, 0x7fffffff, -1); }
-            else           loose_box[i] = make_int4(0, 0x7ffffff0, 0, 0x7ffffff0);       // every pixel
         }
     }
 
@@ -613,235 +622,6 @@ __device__ __forceinline__ bool rect_hits_box(float rx_lo, float rx_hi, float ry
     return !(rx_lo > box.y || rx_hi < box.x || ry_lo > box.w || ry_hi < box.z);
 }
 
-// the cull box of a flagged face from the pixel box loose_faces_kernel left: pixel centres, inclusive (empty: misses everything)
-__device__ __forceinline__ float4 loose_box_ndc(const int4& bx, int is, double r_is)
-{
-    if (bx.x > bx.y || bx.z > bx.w) return make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
-    if (bx.y >= is || bx.w >= is) return make_float4(-INFINITY, INFINITY, -INFINITY, INFINITY);      // every pixel (a full list, see face_setup_kernel)
-    return make_float4(pixel_coord(bx.x, is, r_is), pixel_coord(bx.y, is, r_is), pixel_coord(is - 1 - bx.w, is, r_is), pixel_coord(is - 1 - bx.z, is, r_is));
-}
-
-#ifndef GENDR_BIN_LOOP_MAX
-#define GENDR_BIN_LOOP_MAX 6
-#endif
-#ifndef GENDR_BIN_THREADS
-#define GENDR_BIN_THREADS 512
-#endif
-// ---------------------------------------------------------------------------------------------
-// binning: masks[b][tile][chunk], bit f of chunk c = face 64c+f of image b may touch the 8x8 tile; and the tile
-// queues the render kernels walk.
-// One workgroup takes a block of 8x8 tiles (a 64x64 pixel super-tile) of one image; its wavefronts share the face
-// chunks.  For a chunk, lane = face (coalesced box load) and lane = tile as well: a ballot finds the few faces whose
-// box meets the super-tile at all; for each of them the box is broadcast with v_readlane and every tile lane sets
-// its bit.  The words go to LDS, from where the mask rows leave in runs of 8 tiles x chunks words (the rows of 8
-// horizontally adjacent tiles are contiguous in HBM).  Once all chunks are done the first wavefront knows, per tile,
-// whether its row is empty and appends the tile to its queue: listed tiles grow the queue from the front, the others
-// -- the background, three quarters of the headline scene -- from the back of the queue's slots (the forward kernel
-// writes their pixels in a store-only loop, backward never looks at them).  Two atomics per workgroup.
-// ---------------------------------------------------------------------------------------------
-constexpr int kBinThreads = GENDR_BIN_THREADS, kBinWaves = kBinThreads / 64;
-constexpr int kBinGroup = 32;      // chunks staged in LDS per round
-constexpr int kBinLoopMax = GENDR_BIN_LOOP_MAX;   // up to this many candidate faces of a chunk are broadcast one by one
-
-__device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ float4 bcast4(const float4& v, int l) { return make_float4(bcast(v.x, l), bcast(v.y, l), bcast(v.z, l), bcast(v.w, l)); }
-
-__device__ __forceinline__ int wave_exclusive_scan(int v, int& total)
-{
-    const int lane = threadIdx.x & 63;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-    }
-    total = __builtin_amdgcn_readlane(incl, 63);
-    return incl - v;
-}
-
-__global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BIN_WAVES, GENDR_BIN_WAVES))) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull,
-                                                                                                                        float4* __restrict__ clear4, long clear_quads)
-{
-    // the caller's buffer to clear (gendr_params::clear_ptr: the gradients of the coming backward call): one 16-byte store per
-    // thread or so, issued before anything else -- this kernel has 400 times the threads of the per-face setup kernel (which
-    // did it until round 3 and paid 2.6 us for it: its waves run alone on their SIMDs)
-    for (long q = (long)blockIdx.x * kBinThreads + threadIdx.x; q < clear_quads; q += (long)gridDim.x * kBinThreads)
-        clear4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the lists of faces with a loose cull box have been used (loose_faces_kernel ran before this launch): empty them for the
-    // next call on this workspace
-    if (a.loose_flag && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < a.B; i += kBinThreads) a.loose_image[(long)i * kLooseList] = 0;
-    __shared__ unsigned long long s_words[64][kBinGroup + 1];
-    __shared__ int s_listed[64];
-    GENDR_SPAN_BEGIN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int is = a.is, tiles_x = a.tiles_x, chunks = a.chunks;
-    const int per_image = supers_x * supers_x;
-    // Workgroups start in index order and the ones under the object live four times as long as the ones over the
-    // background (16 against 4 us at C2), so the super-tiles are handed out from the image centre outwards, ring by
-    // ring, all images' first ring first: where the object is roughly centred the long workgroups start first instead
-    // of somewhere in a 10-us dispatch ramp; where it is not, the order is as good as any other.
-    const int nimg = (int)(gridDim.x / per_image);
-    const int b = blockIdx.x % nimg;
-    int sy, sx;
-    {
-        const int r = blockIdx.x / nimg;                        // rank of the super-tile, centre first
-        int n = 2 - (supers_x & 1), inner = 0;                  // side of the centred square that holds ranks < n * n
-        while (n * n <= r) { inner = n * n; n += 2; }
-        const int o = (supers_x - n) >> 1, pos = r - inner;     // the ring is the square's border, origin (o, o)
-        if (n == 1)               { sy = o; sx = o; }
-        else if (pos < n)         { sy = o;         sx = o + pos; }                       // top row
-        else if (pos < 2 * n)     { sy = o + n - 1; sx = o + pos - n; }                   // bottom row
-        else if (pos < 3 * n - 2) { sy = o + 1 + pos - 2 * n;       sx = o; }             // left column
-        else                      { sy = o + 1 + pos - (3 * n - 2); sx = o + n - 1; }     // right column
-    }
-
-    // lane t owns tile t of the super-tile: its rectangle and, at the end, its mask words
-    const int ty_l = sy * 8 + (lane >> 3), tx_l = sx * 8 + (lane & 7);
-    const bool tile_ok = ty_l < tiles_x && tx_l < tiles_x;
-    const float rx_lo = pixel_coord(tx_l * 8, is, a.r_is), rx_hi = pixel_coord(min(tx_l * 8 + 7, is - 1), is, a.r_is);
-    const float ry_hi = pixel_coord(is - 1 - ty_l * 8, is, a.r_is), ry_lo = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is, a.r_is);
-    const float sx_lo = pixel_coord(sx * 64, is, a.r_is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is, a.r_is);
-    const float sy_hi = pixel_coord(is - 1 - sy * 64, is, a.r_is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is, a.r_is);
-    const long tile_base = (long)b * a.tiles_per_image;
-    int listed_faces = 0;                                                    // first wavefront: faces listed for this lane's tile
-
-    for (int c0 = 0; c0 < chunks; c0 += kBinGroup) {
-        const int ng = min(kBinGroup, chunks - c0);
-        constexpr int kPerWave = (kBinGroup + kBinWaves - 1) / kBinWaves;
-#pragma unroll
-        for (int u = 0; u < kPerWave; u++) {
-            const int ci = wave + u * kBinWaves;
-            if (ci >= ng) break;
-            const int fi = (c0 + ci) * 64 + lane;
-            const bool have = fi < a.nf;
-            float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
-            if (have) box = (reinterpret_cast<const float4*>(boxes) + ((long)b * a.nf + fi) * (kBinRec / 4))[0];
-            if (have && a.loose_flag && a.loose_flag[(long)b * a.nf + fi]) box = loose_box_ndc(a.loose_box[(long)b * a.nf + fi], is, a.r_is);
-            unsigned long long mine = 0ull;
-            // Box test only (measured in round 2: an exact per-(face, tile) edge test removes a third of the listings but
-            // costs this kernel 43 us at C2; the coverage kernel drops those faces for 10 us).
-            unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
-            if (__popcll(cand) <= kBinLoopMax) {
-                // a handful: broadcast each box, every tile lane sets its bit
-                while (cand) {
-                    const int l = __builtin_ctzll(cand);
-                    cand &= cand - 1;
-                    const float4 fb = bcast4(box, l);
-                    if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << l;
-                }
-            } else {
-                // many (the super-tiles under the object): the predicate is separable, and the tile columns (rows) a box meets
-                // are one run of the eight.  Every face lane turns its box into the two runs -- in pixel-index space, i =
-                // (x + 1) is / 2 - 1/2, rounded OUTWARDS by 2^-6 pixel (the float error is below 2^-10 pixel up to 4096^2): the
-                // tile masks only have to be a superset, the coverage kernel applies the exact per-pixel box test -- then one
-                // ballot per column and per row (16, not one per tile: 64) and every tile lane picks its column's and its row's
-                // word with lane-constant select masks.  NaN boxes keep every tile, as the comparisons of rect_hits_box() do.
-                unsigned mx = 0xffu, my = 0xffu;
-                if (cull) {
-                    constexpr float kPixSlack = 0.015625f;                             // 2^-6 pixel
-                    const float half_is = 0.5f * (float)is, fis = (float)is;
-                    const float px_lo = (box.x + 1.f) * half_is - 0.5f, px_hi = (box.y + 1.f) * half_is - 0.5f;      // pixel columns of the box
-                    const float pr_lo = fis - 0.5f - (box.w + 1.f) * half_is, pr_hi = fis - 0.5f - (box.z + 1.f) * half_is;   // pixel rows (row 0 = top = largest y)
-                    const float X0 = (float)(sx * 64), Y0 = (float)(sy * 64);
-                    const int kx_lo = (int)fmaxf(ceilf((px_lo - X0 - 7.f - kPixSlack) * 0.125f), 0.f), kx_hi = (int)fminf(floorf((px_hi - X0 + kPixSlack) * 0.125f), 7.f);
-                    const int ky_lo = (int)fmaxf(ceilf((pr_lo - Y0 - 7.f - kPixSlack) * 0.125f), 0.f), ky_hi = (int)fminf(floorf((pr_hi - Y0 + kPixSlack) * 0.125f), 7.f);
-                    mx = kx_hi >= kx_lo && kx_lo <= 7 && kx_hi >= 0 ? ((2u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u) : 0u;
-                    my = ky_hi >= ky_lo && ky_lo <= 7 && ky_hi >= 0 ? ((2u << ky_hi) - 1u) & ~((1u << ky_lo) - 1u) : 0u;
-                }
-                if (!((cand >> lane) & 1ull)) mx = 0u;              // also drops lanes without a face
-                unsigned long long colw = 0ull, roww = 0ull;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const unsigned long long cm = __ballot((mx >> k) & 1u), rm = __ballot((my >> k) & 1u);
-                    if (__builtin_amdgcn_inverse_ballot_w64(0x0101010101010101ull << k)) colw = cm;     // lanes of tile column k
-                    if (__builtin_amdgcn_inverse_ballot_w64(0xffull << (8 * k))) roww = rm;             // lanes of tile row k
-                }
-                mine = colw & roww;
-            }
-            s_words[lane][ci] = mine;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            for (int ci = 0; ci < ng; ci++) listed_faces += __popcll(s_words[lane][ci]);
-            s_listed[lane] = listed_faces != 0;
-        }
-        // Nobody reads the mask row of a tile that lists no face (such a tile is not queued), so when the whole row is
-        // known here -- one group holds all chunks, up to 2048 faces -- the rows of empty tiles are not written at all
-        // (the background: 79 % of the tiles of BASELINE config 5, 265 MB of zeros per call at batch 32).
-        const bool skip_empty = chunks <= kBinGroup;
-        if (skip_empty) __syncthreads();
-        // (no entry pool for this option set, see entry_capacity: nobody reads the masks, and they have no buffer)
-        for (int idx = threadIdx.x; idx < (a.ent_cap8 > 0 ? 64 * ng : 0); idx += kBinThreads) {   // consecutive threads: consecutive words of a row
-            const int tl = idx / ng, ci = idx - tl * ng;
-            const int ty = sy * 8 + (tl >> 3), tx = sx * 8 + (tl & 7);
-            if (ty < tiles_x && tx < tiles_x && (!skip_empty || s_listed[tl]))
-                const_cast<unsigned long long*>(a.masks)[(tile_base + (long)ty * tiles_x + tx) * chunks + c0 + ci] = s_words[tl][ci];
-        }
-        __syncthreads();
-    }
-    if (wave != 0) return;
-
-    // tile queues and the tiles' slices of the entry pool.  Usually the 64 tiles belong to one queue; small batches
-    // of small images put several into one wave
-    const long g = tile_base + (long)ty_l * tiles_x + tx_l;
-    const int xq = tile_ok ? queue_of_tile(g, a.total_tiles) : -1;
-    if (!tile_ok) listed_faces = 0;
-    // A super-tile that lies wholly inside the image and lists nothing anywhere becomes ONE entry of the unlisted
-    // queue, -(its first tile) - 1: the forward kernel fills its 64 x 64 pixels with 256-byte row segments instead of
-    // 64 tiles' 32-byte ones (image rows of a multiple of four pixels, for 16-byte stores).
-    if ((is & 3) == 0 && sx * 64 + 64 <= is && sy * 64 + 64 <= is) {
-        const int x0 = __builtin_amdgcn_readlane(xq, 0);
-        if (__ballot(listed_faces == 0 && xq == x0) == ~0ull) {
-            if (lane == 0) {
-                const int base_e = atomicAdd(a.control + (8 + x0) * kCtlStride, 1);
-                a.tile_list[queue_begin(x0 + 1, a.total_tiles) - 1 - base_e] = -(int)g - 1;
-            }
-            GENDR_SPAN_END(1, blockIdx.x);
-            return;
-        }
-    }
-    unsigned long long todo = __ballot(tile_ok);
-    while (todo) {
-        const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
-        const unsigned long long mine = __ballot(xq == x);
-        todo &= ~mine;
-        const unsigned long long listed = __ballot(xq == x && listed_faces != 0);
-        const unsigned long long empty = mine & ~listed;
-        int need = 0;
-        const int before = wave_exclusive_scan(xq == x ? listed_faces : 0, need);
-        int base_l = 0, base_e = 0;
-        long base_n = 0;
-        if (lane == 0) {
-            if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
-            if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
-            // Entries handed out so far in region x of the pool.  A 64-bit counter that is only advanced while the request
-            // fits: requests beyond the pool (nothing culled: every tile lists every face, 2.7e9 listings at 2048^2 x 5120
-            // faces x 64) cannot wrap it and land in another region's slice; a request that finds the region exhausted gets
-            // ent_cap8, i.e. no slice (ent_cap8 == 0: this option set has no pool at all, see entry_capacity).
-            if (need) {
-                unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.control + (16 + x) * kCtlStride);
-                base_n = a.ent_cap8;
-                if (a.ent_cap8 > 0 && (long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + need <= a.ent_cap8)
-                    base_n = (long)atomicAdd(ctr, (unsigned long long)need);
-            }
-        }
-        base_l = __builtin_amdgcn_readfirstlane(base_l);
-        base_e = __builtin_amdgcn_readfirstlane(base_e);
-        base_n = ((long)__builtin_amdgcn_readfirstlane((int)(base_n >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base_n);
-        if ((listed >> lane) & 1ull) {
-            const long slot = queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt);
-            const long at = base_n + before;                                    // inside region x of the pool
-            const int off = (at >= 0 && at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL) ? (int)((long)x * a.ent_cap8 + at) : -1;
-            a.tile_list[slot] = (int)g;
-            a.tile_info_raw[slot] = make_int4((int)g, off, 0, 0);               // the coverage kernel fills in the entry count
-        }
-        if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
-    }
-    GENDR_SPAN_END(1, blockIdx.x);
-}
-
 // ---------------------------------------------------------------------------------------------
 // wave-tile bookkeeping shared by forward and backward
 // ---------------------------------------------------------------------------------------------
@@ -858,7 +638,7 @@ struct TileCtx {
 // The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
 // own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
 // tiles list a face) that is one tile per wave and no wave is launched in vain.
-struct TileWalk { long qbase, qend; int total, empties, rank, next, stride, split_log2, hint_flag; };
+struct TileWalk { long qbase, qend; int total, live, empties, rank, next, stride, split_log2, hint_flag; };
 
 // Sub-tile split of the render kernels.  The latency of a launch is the latency of one wave on the heaviest tile (ten
 // batches at the headline scene); when a queue lists fewer tiles than the chip holds waves for it at once (resident_q, from
@@ -874,7 +654,7 @@ struct TileWalk { long qbase, qend; int total, empties, rank, next, stride, spli
 __device__ __forceinline__ int walk_split_log2(const TileWalk& w, int resident_q)
 {
     int s = 0;
-    while (s < GENDR_SPLIT_MAX_LOG2 && ((long)w.total << (s + 1)) <= (long)min(w.stride, resident_q + (resident_q >> 2))) s++;
+    while (s < GENDR_SPLIT_MAX_LOG2 && ((long)w.live << (s + 1)) <= (long)min(w.stride, resident_q + (resident_q >> 2))) s++;
     return s;
 }
 // pixel lanes (bits) of sub-tile `sub` of 1 << split_log2: whole rows of 8 pixels
@@ -891,6 +671,8 @@ __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int 
     w.qbase = queue_begin(xcd, a.total_tiles);
     w.qend = queue_begin(xcd + 1, a.total_tiles);
     w.total = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride]);
+    // (the render kernels walk the heavy-first copy when there is one: its tiles without any entry sit at the end)
+    w.live = a.tile_info != a.tile_info_raw ? __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride + kCtlLive]) : w.total;
     w.empties = __builtin_amdgcn_readfirstlane(a.control[(8 + xcd) * kCtlStride]);
     w.hint_flag = __builtin_amdgcn_readfirstlane(a.control[xcd * kCtlStride + kCtlHintFlag]);
     w.stride = (int)(gridDim.x >> 3) * waves_per_block;
@@ -1233,6 +1015,14 @@ __device__ __forceinline__ unsigned long long collect_pairs(const TileCtx& t, Re
     return __ballot(live);
 }
 
+// the cull box of a flagged face from the pixel box loose_faces_kernel left: pixel centres, inclusive (empty: misses everything)
+__device__ __forceinline__ float4 loose_box_ndc(const int4& bx, int is, double r_is)
+{
+    if (bx.x > bx.y || bx.z > bx.w) return make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    if (bx.y >= is || bx.w >= is) return make_float4(-INFINITY, INFINITY, -INFINITY, INFINITY);      // every pixel (a full list, see face_setup_kernel)
+    return make_float4(pixel_coord(bx.x, is, r_is), pixel_coord(bx.y, is, r_is), pixel_coord(is - 1 - bx.w, is, r_is), pixel_coord(is - 1 - bx.z, is, r_is));
+}
+
 // ---------------------------------------------------------------------------------------------
 // faces with a loose cull box (face_setup_kernel): the bounding box of the pixels that can contribute
 // ---------------------------------------------------------------------------------------------
@@ -1321,6 +1111,227 @@ __global__ __launch_bounds__(kThreads) void loose_faces_kernel(const RenderArgs 
     }
 }
 
+#ifndef GENDR_BIN_LOOP_MAX
+#define GENDR_BIN_LOOP_MAX 6
+#endif
+#ifndef GENDR_BIN_THREADS
+#define GENDR_BIN_THREADS 512
+#endif
+// ---------------------------------------------------------------------------------------------
+// binning: masks[b][tile][chunk], bit f of chunk c = face 64c+f of image b may touch the 8x8 tile; and the tile
+// queues the render kernels walk.
+// One workgroup takes a block of 8x8 tiles (a 64x64 pixel super-tile) of one image; its wavefronts share the face
+// chunks.  For a chunk, lane = face (coalesced box load) and lane = tile as well: a ballot finds the few faces whose
+// box meets the super-tile at all; for each of them the box is broadcast with v_readlane and every tile lane sets
+// its bit.  The words go to LDS, from where the mask rows leave in runs of 8 tiles x chunks words (the rows of 8
+// horizontally adjacent tiles are contiguous in HBM).  Once all chunks are done the first wavefront knows, per tile,
+// whether its row is empty and appends the tile to its queue: listed tiles grow the queue from the front, the others
+// -- the background, three quarters of the headline scene -- from the back of the queue's slots (the forward kernel
+// writes their pixels in a store-only loop, backward never looks at them).  Two atomics per workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBinThreads = GENDR_BIN_THREADS, kBinWaves = kBinThreads / 64;
+constexpr int kBinGroup = 32;      // chunks staged in LDS per round
+constexpr int kBinLoopMax = GENDR_BIN_LOOP_MAX;   // up to this many candidate faces of a chunk are broadcast one by one
+
+__device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float4 bcast4(const float4& v, int l) { return make_float4(bcast(v.x, l), bcast(v.y, l), bcast(v.z, l), bcast(v.w, l)); }
+
+__device__ __forceinline__ int wave_exclusive_scan(int v, int& total)
+{
+    const int lane = threadIdx.x & 63;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    total = __builtin_amdgcn_readlane(incl, 63);
+    return incl - v;
+}
+
+__global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GENDR_BIN_WAVES, GENDR_BIN_WAVES))) void bin_faces_kernel(const float* __restrict__ boxes, const RenderArgs a, int supers_x, int cull,
+                                                                                                                        float4* __restrict__ clear4, long clear_quads)
+{
+    // the caller's buffer to clear (gendr_params::clear_ptr: the gradients of the coming backward call): one 16-byte store per
+    // thread or so, issued before anything else -- this kernel has 400 times the threads of the per-face setup kernel (which
+    // did it until round 3 and paid 2.6 us for it: its waves run alone on their SIMDs)
+    for (long q = (long)blockIdx.x * kBinThreads + threadIdx.x; q < clear_quads; q += (long)gridDim.x * kBinThreads)
+        clear4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the lists of faces with a loose cull box have been used (loose_faces_kernel ran before this launch): empty them for the
+    // next call on this workspace
+    if (a.loose_flag && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.B; i += kBinThreads) a.loose_image[(long)i * kLooseList] = 0;
+    __shared__ unsigned long long s_words[64][kBinGroup + 1];
+    __shared__ int s_listed[64];
+    GENDR_SPAN_BEGIN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int is = a.is, tiles_x = a.tiles_x, chunks = a.chunks;
+    const int per_image = supers_x * supers_x;
+    // Workgroups start in index order and the ones under the object live four times as long as the ones over the
+    // background (16 against 4 us at C2), so the super-tiles are handed out from the image centre outwards, ring by
+    // ring, all images' first ring first: where the object is roughly centred the long workgroups start first instead
+    // of somewhere in a 10-us dispatch ramp; where it is not, the order is as good as any other.
+    const int nimg = (int)(gridDim.x / per_image);
+    const int b = blockIdx.x % nimg;
+    int sy, sx;
+    {
+        const int r = blockIdx.x / nimg;                        // rank of the super-tile, centre first
+        int n = 2 - (supers_x & 1), inner = 0;                  // side of the centred square that holds ranks < n * n
+        while (n * n <= r) { inner = n * n; n += 2; }
+        const int o = (supers_x - n) >> 1, pos = r - inner;     // the ring is the square's border, origin (o, o)
+        if (n == 1)               { sy = o; sx = o; }
+        else if (pos < n)         { sy = o;         sx = o + pos; }                       // top row
+        else if (pos < 2 * n)     { sy = o + n - 1; sx = o + pos - n; }                   // bottom row
+        else if (pos < 3 * n - 2) { sy = o + 1 + pos - 2 * n;       sx = o; }             // left column
+        else                      { sy = o + 1 + pos - (3 * n - 2); sx = o + n - 1; }     // right column
+    }
+
+    // lane t owns tile t of the super-tile: its rectangle and, at the end, its mask words
+    const int ty_l = sy * 8 + (lane >> 3), tx_l = sx * 8 + (lane & 7);
+    const bool tile_ok = ty_l < tiles_x && tx_l < tiles_x;
+    const float rx_lo = pixel_coord(tx_l * 8, is, a.r_is), rx_hi = pixel_coord(min(tx_l * 8 + 7, is - 1), is, a.r_is);
+    const float ry_hi = pixel_coord(is - 1 - ty_l * 8, is, a.r_is), ry_lo = pixel_coord(is - 1 - min(ty_l * 8 + 7, is - 1), is, a.r_is);
+    const float sx_lo = pixel_coord(sx * 64, is, a.r_is), sx_hi = pixel_coord(min(sx * 64 + 63, is - 1), is, a.r_is);
+    const float sy_hi = pixel_coord(is - 1 - sy * 64, is, a.r_is), sy_lo = pixel_coord(is - 1 - min(sy * 64 + 63, is - 1), is, a.r_is);
+    const long tile_base = (long)b * a.tiles_per_image;
+    int listed_faces = 0;                                                    // first wavefront: faces listed for this lane's tile
+
+    for (int c0 = 0; c0 < chunks; c0 += kBinGroup) {
+        const int ng = min(kBinGroup, chunks - c0);
+        constexpr int kPerWave = (kBinGroup + kBinWaves - 1) / kBinWaves;
+#pragma unroll
+        for (int u = 0; u < kPerWave; u++) {
+            const int ci = wave + u * kBinWaves;
+            if (ci >= ng) break;
+            const int fi = (c0 + ci) * 64 + lane;
+            const bool have = fi < a.nf;
+            float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
+            if (have) box = (reinterpret_cast<const float4*>(boxes) + ((long)b * a.nf + fi) * (kBinRec / 4))[0];
+            if (have && a.loose_flag && a.loose_flag[(long)b * a.nf + fi]) box = loose_box_ndc(a.loose_box[(long)b * a.nf + fi], is, a.r_is);
+            unsigned long long mine = 0ull;
+            // Box test only (measured in round 2: an exact per-(face, tile) edge test removes a third of the listings but
+            // costs this kernel 43 us at C2; the coverage kernel drops those faces for 10 us).
+            unsigned long long cand = __ballot(have && (cull ? rect_hits_box(sx_lo, sx_hi, sy_lo, sy_hi, box) : true));
+            if (__popcll(cand) <= kBinLoopMax) {
+                // a handful: broadcast each box, every tile lane sets its bit
+                while (cand) {
+                    const int l = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    const float4 fb = bcast4(box, l);
+                    if (cull ? rect_hits_box(rx_lo, rx_hi, ry_lo, ry_hi, fb) : true) mine |= 1ull << l;
+                }
+            } else {
+                // many (the super-tiles under the object): the predicate is separable, and the tile columns (rows) a box meets
+                // are one run of the eight.  Every face lane turns its box into the two runs -- in pixel-index space, i =
+                // (x + 1) is / 2 - 1/2, rounded OUTWARDS by 2^-6 pixel (the float error is below 2^-10 pixel up to 4096^2): the
+                // tile masks only have to be a superset, the coverage kernel applies the exact per-pixel box test -- then one
+                // ballot per column and per row (16, not one per tile: 64) and every tile lane picks its column's and its row's
+                // word with lane-constant select masks.  NaN boxes keep every tile, as the comparisons of rect_hits_box() do.
+                unsigned mx = 0xffu, my = 0xffu;
+                if (cull) {
+                    constexpr float kPixSlack = 0.015625f;                             // 2^-6 pixel
+                    const float half_is = 0.5f * (float)is, fis = (float)is;
+                    const float px_lo = (box.x + 1.f) * half_is - 0.5f, px_hi = (box.y + 1.f) * half_is - 0.5f;      // pixel columns of the box
+                    const float pr_lo = fis - 0.5f - (box.w + 1.f) * half_is, pr_hi = fis - 0.5f - (box.z + 1.f) * half_is;   // pixel rows (row 0 = top = largest y)
+                    const float X0 = (float)(sx * 64), Y0 = (float)(sy * 64);
+                    const int kx_lo = (int)fmaxf(ceilf((px_lo - X0 - 7.f - kPixSlack) * 0.125f), 0.f), kx_hi = (int)fminf(floorf((px_hi - X0 + kPixSlack) * 0.125f), 7.f);
+                    const int ky_lo = (int)fmaxf(ceilf((pr_lo - Y0 - 7.f - kPixSlack) * 0.125f), 0.f), ky_hi = (int)fminf(floorf((pr_hi - Y0 + kPixSlack) * 0.125f), 7.f);
+                    mx = kx_hi >= kx_lo && kx_lo <= 7 && kx_hi >= 0 ? ((2u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u) : 0u;
+                    my = ky_hi >= ky_lo && ky_lo <= 7 && ky_hi >= 0 ? ((2u << ky_hi) - 1u) & ~((1u << ky_lo) - 1u) : 0u;
+                }
+                if (!((cand >> lane) & 1ull)) mx = 0u;              // also drops lanes without a face
+                unsigned long long colw = 0ull, roww = 0ull;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const unsigned long long cm = __ballot((mx >> k) & 1u), rm = __ballot((my >> k) & 1u);
+                    if (__builtin_amdgcn_inverse_ballot_w64(0x0101010101010101ull << k)) colw = cm;     // lanes of tile column k
+                    if (__builtin_amdgcn_inverse_ballot_w64(0xffull << (8 * k))) roww = rm;             // lanes of tile row k
+                }
+                mine = colw & roww;
+            }
+            s_words[lane][ci] = mine;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int ci = 0; ci < ng; ci++) listed_faces += __popcll(s_words[lane][ci]);
+            s_listed[lane] = listed_faces != 0;
+        }
+        // Nobody reads the mask row of a tile that lists no face (such a tile is not queued), so when the whole row is
+        // known here -- one group holds all chunks, up to 2048 faces -- the rows of empty tiles are not written at all
+        // (the background: 79 % of the tiles of BASELINE config 5, 265 MB of zeros per call at batch 32).
+        const bool skip_empty = chunks <= kBinGroup;
+        if (skip_empty) __syncthreads();
+        // (no entry pool for this option set, see entry_capacity: nobody reads the masks, and they have no buffer)
+        for (int idx = threadIdx.x; idx < (a.ent_cap8 > 0 ? 64 * ng : 0); idx += kBinThreads) {   // consecutive threads: consecutive words of a row
+            const int tl = idx / ng, ci = idx - tl * ng;
+            const int ty = sy * 8 + (tl >> 3), tx = sx * 8 + (tl & 7);
+            if (ty < tiles_x && tx < tiles_x && (!skip_empty || s_listed[tl]))
+                const_cast<unsigned long long*>(a.masks)[(tile_base + (long)ty * tiles_x + tx) * chunks + c0 + ci] = s_words[tl][ci];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+
+    // tile queues and the tiles' slices of the entry pool.  Usually the 64 tiles belong to one queue; small batches
+    // of small images put several into one wave
+    const long g = tile_base + (long)ty_l * tiles_x + tx_l;
+    const int xq = tile_ok ? queue_of_tile(g, a.total_tiles) : -1;
+    if (!tile_ok) listed_faces = 0;
+    // A super-tile that lies wholly inside the image and lists nothing anywhere becomes ONE entry of the unlisted
+    // queue, -(its first tile) - 1: the forward kernel fills its 64 x 64 pixels with 256-byte row segments instead of
+    // 64 tiles' 32-byte ones (image rows of a multiple of four pixels, for 16-byte stores).
+    if ((is & 3) == 0 && sx * 64 + 64 <= is && sy * 64 + 64 <= is) {
+        const int x0 = __builtin_amdgcn_readlane(xq, 0);
+        if (__ballot(listed_faces == 0 && xq == x0) == ~0ull) {
+            if (lane == 0) {
+                const int base_e = atomicAdd(a.control + (8 + x0) * kCtlStride, 1);
+                a.tile_list[queue_begin(x0 + 1, a.total_tiles) - 1 - base_e] = -(int)g - 1;
+            }
+            GENDR_SPAN_END(1, blockIdx.x);
+            return;
+        }
+    }
+    unsigned long long todo = __ballot(tile_ok);
+    while (todo) {
+        const int x = __builtin_amdgcn_readlane(xq, __builtin_ctzll(todo));
+        const unsigned long long mine = __ballot(xq == x);
+        todo &= ~mine;
+        const unsigned long long listed = __ballot(xq == x && listed_faces != 0);
+        const unsigned long long empty = mine & ~listed;
+        int need = 0;
+        const int before = wave_exclusive_scan(xq == x ? listed_faces : 0, need);
+        int base_l = 0, base_e = 0;
+        long base_n = 0;
+        if (lane == 0) {
+            if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
+            if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
+            // Entries handed out so far in region x of the pool.  A 64-bit counter that is only advanced while the request
+            // fits: requests beyond the pool (nothing culled: every tile lists every face, 2.7e9 listings at 2048^2 x 5120
+            // faces x 64) cannot wrap it and land in another region's slice; a request that finds the region exhausted gets
+            // ent_cap8, i.e. no slice (ent_cap8 == 0: this option set has no pool at all, see entry_capacity).
+            if (need) {
+                unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.control + (16 + x) * kCtlStride);
+                base_n = a.ent_cap8;
+                if (a.ent_cap8 > 0 && (long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + need <= a.ent_cap8)
+                    base_n = (long)atomicAdd(ctr, (unsigned long long)need);
+            }
+        }
+        base_l = __builtin_amdgcn_readfirstlane(base_l);
+        base_e = __builtin_amdgcn_readfirstlane(base_e);
+        base_n = ((long)__builtin_amdgcn_readfirstlane((int)(base_n >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base_n);
+        if ((listed >> lane) & 1ull) {
+            const long slot = queue_begin(x, a.total_tiles) + base_l + __popcll(listed & lt);
+            const long at = base_n + before;                                    // inside region x of the pool
+            const int off = (at >= 0 && at + listed_faces <= a.ent_cap8 && (long)x * a.ent_cap8 + at < 0x7fffffffL) ? (int)((long)x * a.ent_cap8 + at) : -1;
+            a.tile_list[slot] = (int)g;
+            a.tile_info_raw[slot] = make_int4((int)g, off, 0, 0);               // the coverage kernel fills in the entry count
+        }
+        if ((empty >> lane) & 1ull)  a.tile_list[queue_begin(x + 1, a.total_tiles) - 1 - (base_e + __popcll(empty & lt))] = (int)g;
+    }
+    GENDR_SPAN_END(1, blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // coverage: which pixels of the tile does each listed face reach?  (once per forward call, shared by both passes)
 // ---------------------------------------------------------------------------------------------
@@ -1403,10 +1414,6 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 const int fn = s_flist[has ? i0 + slot : i0];
                 float r[kRecStage1];
                 gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
-                if (has && __float_as_int(r[kRecLoose]) != 0) {             // a loose cull box: the one loose_faces_kernel found instead
-                    const float4 lb = loose_box_ndc(a.loose_box[(long)t.b * a.nf + fn], a.is, a.r_is);
-                    r[kRecBox + 0] = lb.x; r[kRecBox + 1] = lb.y; r[kRecBox + 2] = lb.z; r[kRecBox + 3] = lb.w;
-                }
                 unsigned m8 = 0u;
                 // The entries only have to be a SUPERSET of the contributing pairs (every pair still meets the reference's own
                 // skip tests in the render kernels).  Along a pixel row each barycentric is linear in the column c = 0..7,
@@ -1446,9 +1453,39 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                     const int c_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(hi, -2.f) + kColSlack));
                     if (!none && c_last >= c_first) m8 = ((2u << c_last) - 1u) & ~((1u << c_first) - 1u);
                 }
+                const bool loose_l = has && __float_as_int(r[kRecLoose]) != 0;         // (the eight lanes of a slot hold the same record)
+                if (loose_l) m8 = 0u;
+                unsigned v = quad_or(m8 << (8 * (prow & 3)));            // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
+                unsigned hi = (unsigned)__shfl_down((int)v, 4);                        // lane 8s reads lane 8s+4 (rows 4-7)
+                // A face with a LOOSE cull box (face_setup_kernel: seen edge-on, no usable error bound -- its box is the reference's
+                // own margin and the binning kernel listed it in every tile of its image) is EVALUATED instead of bounded: lane =
+                // pixel of the tile, the record in scalar registers, barycentrics() and point_to_face() -- the render kernels'
+                // functions on the same operands -- and the pixel is LIVE if it lies inside the record's box and inside the face or
+                // closer to it than the cull radius (beyond the radius the pair fails :769 or :784, which is what the radius is
+                // defined by; NaN barycentrics drop the pair as everywhere).  The render kernels still apply the reference's own
+                // tests to every listed pair, so the mask only has to contain the pixels that can contribute -- it contains exactly
+                // the live ones, and a tile without any drops the face.  (Round 3 ran a launch of its own for this -- every pixel
+                // of the image once, leaving a bounding box for the binning kernel -- which cost 5-10 us per call and was therefore
+                // switched on from 1024^2 only; here it costs the affected tiles' waves ~1 us per flagged face, spread over the
+                // whole chip, and nothing anywhere else.)
+                unsigned long long flagged = __ballot(loose_l && prow == 0);
+                while (flagged) {
+                    const int l = __builtin_ctzll(flagged);
+                    flagged &= flagged - 1;
+                    const int fn_l = __builtin_amdgcn_readlane(fn, l);
+                    float rl[kRecStage3];
+                    load_record<0, kRecStage3>(rl, (RecPtr)recs_g + (long)fn_l * REC);
+                    Pair q;
+                    barycentrics(q, rl, t.xp, t.yp);
+                    bool live = false;
+                    if (t.valid && inside_box(rl, t.xp, t.yp)) {
+                        live = inside_closed(q);                                       // (closed: what the heaviside branch of soft_fragment tests)
+                        if (!live && point_to_face(q, rl, t.xp, t.yp)) live = q.sign > 0.f || q.dx * q.dx + q.dy * q.dy < a.cull_r2;
+                    }
+                    const unsigned long long lm = __ballot(live);
+                    if (lane == l) { v = (unsigned)lm; hi = (unsigned)(lm >> 32); my_pairs += __popcll(lm); }
+                }
                 my_pairs += __popc(m8);
-                const unsigned v = quad_or(m8 << (8 * (prow & 3)));      // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
-                const unsigned hi = (unsigned)__shfl_down((int)v, 4);                  // lane 8s reads lane 8s+4 (rows 4-7)
                 const bool owns = prow == 0 && (v | hi) != 0u;
                 const unsigned long long keep = __ballot(owns);
                 if (owns) {
@@ -1490,6 +1527,13 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
 // L2 (C5, 2.1 M tiles at batch 32: 3.5 % slower when ordered).
 constexpr int kOrderThreads = 1024, kOrderClasses = 32;
 constexpr long kOrderTilesMax = 1L << 19;
+// weight class of a queue record (tile, first entry, entries, pairs): 0 = no entries at all (a tile with a slice of the pool
+// whose list came out empty), else 1 + pairs / 32, capped
+__device__ __forceinline__ int order_class(const int4& rec)
+{
+    if (rec.y >= 0 && rec.z == 0) return 0;
+    return min((rec.w >> 5) + 1, kOrderClasses - 1);
+}
 
 __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const RenderArgs a)
 {
@@ -1500,16 +1544,20 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
     if (threadIdx.x < kOrderClasses) s_count[threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kOrderThreads)
-        atomicAdd(&s_count[min(a.tile_info_raw[qbase + i].w >> 5, kOrderClasses - 1)], 1);
+        atomicAdd(&s_count[order_class(a.tile_info_raw[qbase + i])], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int at = 0;
         for (int c = kOrderClasses - 1; c >= 0; c--) { s_cursor[c] = at; at += s_count[c]; }
+        // class 0 = tiles whose coverage list came out EMPTY (every face the binning kernel listed for them was dropped by the
+        // exact tests -- the tiles of an image that only a face with a loose cull box reaches): they end up behind all others,
+        // and the render kernels treat them as unlisted (kCtlLive = the number of tiles before them)
+        a.control[x * kCtlStride + kCtlLive] = n - s_count[0];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kOrderThreads) {
         const int4 rec = a.tile_info_raw[qbase + i];
-        a.tile_info[qbase + atomicAdd(&s_cursor[min(rec.w >> 5, kOrderClasses - 1)], 1)] = rec;
+        a.tile_info[qbase + atomicAdd(&s_cursor[order_class(rec)], 1)] = rec;
     }
 }
 
@@ -1689,11 +1737,16 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     }
 #endif
 
+#if GENDR_ABLATE != 5
+    // listed tiles whose coverage list came out empty (behind the live ones in the heavy-first copy): background as well
+    for (int r = tw.live + tw.rank; r < tw.total; r += tw.stride)
+        fill_tile(__builtin_amdgcn_readfirstlane(a.tile_info[tw.qbase + r].x));
+#endif
     tw.split_log2 = walk_split_log2(tw, a.resident_q);
     // pair hints for backward (PairHints): written while no tile of the queue is split among several waves
     const bool hints_q = a.hints != nullptr && tw.split_log2 == 0;
     if (hints_q && tw.rank == 0 && (threadIdx.x & 63) == 0) atomicOr(a.control + (blockIdx.x & 7) * kCtlStride + kCtlHintFlag, 1);
-    for (; tw.next < (tw.total << tw.split_log2); tw.next += tw.stride) {
+    for (; tw.next < (tw.live << tw.split_log2); tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
@@ -2158,10 +2211,11 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     // the forward kernel's pair hints hold for this queue if it rendered the queue unsplit (and met no pair a hint cannot
     // describe) and this kernel does not split either: batch k of a tile is then the same 64 pairs in both
     const bool hinted_q = a.hints != nullptr && tw.hint_flag == 1 && tw.split_log2 == 0;
-    for (; tw.next < (tw.total << tw.split_log2); tw.next += tw.stride) {
+    for (; tw.next < (tw.live << tw.split_log2); tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
+    if (ti.y >= 0 && ti.z == 0) continue;                       // an empty coverage list (no heavy-first copy: such tiles are not sorted out)
     const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
     const PairHints* hint_slot = (hinted_q && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's hints
     if (hint_slot && ti.w <= 4 * 64) {

@@ -95,11 +95,11 @@ typedef struct gendr_params {
                                       alone leaves none and gendr_backward then repeats the search. */
     int   loose_faces;             /* Faces whose cull box is loose -- the error bound of the exact culling dwarfs the cull radius: the
                                       determinant is clamped or tiny, the face is seen edge-on -- would be listed, with every pixel,
-                                      in every tile of their image.  With this on, gendr_forward / gendr_face_setup evaluate such a
-                                      face once on every pixel of its image (one more launch, the render kernels' own pair
-                                      functions) and bin it by the bounding box of the pixels that can contribute at all.  Results
-                                      are the same either way.  0 (default): on for images of at least 1024^2 pixels, where one
-                                      such face costs 65 536 tile listings and the launch is noise; 1: on; -1: off. */
+                                      in every tile of their image.  With this on, the binning stage of gendr_forward /
+                                      gendr_face_setup evaluates such a face on the pixels of its image (the render kernels' own pair
+                                      functions) and lists it only in the tiles that hold a pixel which can contribute at all.
+                                      Results are the same either way.  0 (default) and 1: on (since round 4 it is part of the binning
+                                      kernel and costs nothing where no face is flagged); -1: off. */
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward

@@ -80,8 +80,8 @@ def test_shard_range_uneven():
 
 def test_bench_launcher_world2_stub():
     """`bench.py --gpus 2` outside torchrun starts its own two ranks (gloo, stub step: no GPU here) and rank 0
-    prints one JSON line with n_gpus == 2, weak scaling (the config's batch per rank) as the headline, plus the strong figure (the
-    batch sharded) under extra."""
+    prints one JSON line with n_gpus == 2, STRONG scaling (the config's batch sharded evenly: SURVEY 8(d)) as the headline, plus the
+    weak figure (the config's batch per rank) under extra."""
     import json
     import subprocess
     import sys
@@ -95,8 +95,8 @@ def test_bench_launcher_world2_stub():
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout
     j = json.loads(lines[0])
-    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 3 and j['warmup'] == 1
-    assert j['config']['global_batch'] == 12 and j['extra']['strong']['global_batch'] == 6
+    assert j['n_gpus'] == 2 and j['scaling'] == 'strong' and j['steps'] == 3 and j['warmup'] == 1
+    assert j['config']['global_batch'] == 6 and j['extra']['weak']['global_batch'] == 12
     assert j['value'] > 0 and j['unit'] == 'frames/s'
 
 

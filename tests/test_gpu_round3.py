@@ -206,9 +206,10 @@ LOOSE_CASES = [(n, o) for n, o in scenes.OPTION_MATRIX if n in (
 @pytest.mark.parametrize("name,opts", LOOSE_CASES, ids=[n for n, _ in LOOSE_CASES])
 def test_loose_face_boxes_change_nothing(native_lib, name, opts):
     """gendr_params.loose_faces (ABI 6): a face whose cull box is loose (error bound >> cull radius: the sliver and soup scenes are
-    full of them) is evaluated once on every pixel of its image and binned by the bounding box of the pixels that can contribute
-    at all -- instead of being listed in every tile its loose box meets.  Forced on at these small sizes (automatic from 1024^2):
-    forward results bit-identical to the call without it AND to the all-pairs traversal; gradients equal up to atomics order."""
+    full of them) is evaluated by the coverage kernel on the pixels of every tile its loose box meets and keeps exactly the
+    pixels that can contribute -- instead of all 64 of every such tile.  On by default at every size since round 4: forward
+    results bit-identical to the call without it (loose_faces = -1) AND to the all-pairs traversal; gradients equal up to
+    atomics order."""
     for maker, isz in ((scenes.slivers, 64), (scenes.soup, 48), (scenes.sphere, 64)):
         fv, tex = _inputs(opts, maker)
         grad = np.random.RandomState(4).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
@@ -223,10 +224,10 @@ def test_loose_face_boxes_change_nothing(native_lib, name, opts):
             assert float(np.abs(on[k] - off[k]).max()) <= 2e-5 * scale, (name, maker.__name__, k)
 
 
-def test_loose_face_lists_survive_graph_replay(native_lib):
-    """The per-image lists of loose faces are emptied by the binning kernel after use, so the replay of a captured HIP graph --
-    same kernel arguments, same workspace, over and over -- starts every time from empty lists (a per-call stamp, the first
-    design, made them grow by the image's faces with every replay until they were full)."""
+def test_loose_faces_survive_graph_replay(native_lib):
+    """Loose faces are resolved inside the coverage kernel (round 4; round 3 kept per-image lists that a replayed graph -- same
+    kernel arguments, same workspace, over and over -- could make grow): forty replays of a captured forward call return the
+    first call's image."""
     from gendr_amd.functional import renderer as R
     fv, tex = scenes.slivers()
     isz = 64
@@ -249,8 +250,3 @@ def test_loose_face_lists_survive_graph_replay(native_lib):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(rgba, want)
-    w = ws.cpu().numpy()
-    a256 = lambda v: (v + 255) // 256 * 256
-    control_off = len(w) - 24 * 1024 * 4
-    heads = w[control_off - a256(Bn * 16 * 4):control_off].view(np.int32).reshape(-1, 16)[:Bn, 0]
-    assert (heads == 0).all(), heads
