@@ -5,6 +5,7 @@
 // stream (the reference uses the null stream, kernel.cu:1103,1118,1190), invalid options are rejected
 // with an error code instead of a device printf + NaN, nothing is allocated here.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <math.h>
 #include <string.h>
@@ -287,25 +288,30 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     return texm;
 }
 
-// Grid of a render kernel: a quarter of one-wave-per-tile (waves stride over their queue), but never fewer than 16384
-// waves (or four per tile) -- small batches are bound by the longest wave, not by the number of waves
-// (measured at 256^2: batch 8 179 -> 136 us per step, batch 16 192 -> 154 us, batch 32 226 -> 208 us; batch 64 is the
-// quarter) -- and a multiple of 8 so that every XCD gets the same number of workgroups.
+// Grid of a render kernel / the coverage kernel, in one-wave workgroups: wave r of XCD x takes work items r, r + stride, ... of
+// queue x, so the grid only has to hold the work items of the longest queue -- and every wave beyond that costs dispatch time:
+// the dispatcher issues 600-1000 waves per microsecond, so the 16 384-wave floor of rounds 1-3 put 16-27 us under every
+// launch of a small batch (measured in round 4 at batch 8: render kernels 27 / 30 us whatever the tiles were split into).
+// Per queue (an eighth of the tiles):
+//   * a quarter of its tiles (large batches: at most a quarter to a third of the tiles list a face -- one tile per wave, no
+//     wave launched in vain; measured: 64 > 128 > 256 > 512 threads per workgroup, a quarter > a half),
+//   * but one wave per tile up to 2048 of them (small batches are bound by the longest wave, not by the number of waves:
+//     batch 16 192 -> 154 us per step in round 1),
+//   * and never fewer than the work items the graded sub-tile split may create (`split_items`, see split_budget).
+// A multiple of 8 so that every XCD gets the same number of workgroups.
 #ifndef GENDR_GRID_DIV
 #define GENDR_GRID_DIV 4
 #endif
-#ifndef GENDR_GRID_MIN
-#define GENDR_GRID_MIN 16384
+#ifndef GENDR_GRID_ONE
+#define GENDR_GRID_ONE 2048
 #endif
-int render_blocks(int total_blocks)
+int render_blocks(int total_blocks, int split_items = 0)
 {
-    int blocks = (total_blocks + GENDR_GRID_DIV - 1) / GENDR_GRID_DIV;
-    // up to four waves per tile below GENDR_GRID_MIN: the spare waves split the listed tiles by pixel rows (walk_split_log2)
-    const long four = 4L * total_blocks;
-    const int floor_ = four < GENDR_GRID_MIN ? (int)four : GENDR_GRID_MIN;
-    if (blocks < floor_) blocks = floor_;
-    if (blocks < 1) blocks = 1;
-    return ((blocks + 7) / 8) * 8;
+    const int per_queue = (total_blocks + 7) / 8;
+    int waves = (per_queue + GENDR_GRID_DIV - 1) / GENDR_GRID_DIV;
+    waves = std::max(waves, std::min(per_queue, GENDR_GRID_ONE));
+    waves = std::max(waves, split_items);
+    return 8 * std::max(waves, 1);
 }
 
 // Waves of a render kernel the chip holds at once, per tile queue: occupancy (one-wave workgroups per CU) x CUs / 8.
@@ -327,6 +333,16 @@ int resident_per_queue(render_kernel_t k)
     if (getenv("GENDR_DEBUG")) fprintf(stderr, "gendr: resident_per_queue per_cu %d cus %d -> %d\n", per_cu, cus, v);
     if (used < 16) cache[used++] = Slot{k, dev, v};
     return v;
+}
+
+// Work items (tile pieces) per queue the graded sub-tile split may create (order_tiles_kernel): what the chip holds of the
+// render kernel with the smaller occupancy at once, plus a quarter (the pieces are uneven).  Both render kernels walk the same
+// grades (the pair hints depend on it), and both are launched with at least that many waves per queue.
+int split_budget(const gendr_params* p, int texm, bool silhouette)
+{
+    const KernelEntry& k = pick_kernel(p, texm, silhouette);
+    const int r = std::min(resident_per_queue(k.fwd), resident_per_queue(k.bwd));
+    return r + (r >> 2);
 }
 
 int check_launch()
@@ -490,6 +506,9 @@ float gendr_cull_radius(const gendr_params* p)
     return r;
 }
 
+static int face_setup_impl(const float* faces, const float* textures, void* workspace,
+                           int B, int nf, int T, const gendr_params* p, void* stream, bool silhouette);
+
 // ---- alpha-only rendering (SURVEY f-4) ------------------------------------------------------------------------------
 // The workspace is laid out for T = 4 surface texels, i.e. texture mode kTexSurfaceN: records without texels; no
 // texture pointer is ever dereferenced by the alpha-only kernels.
@@ -511,7 +530,7 @@ int gendr_silhouette_forward(const float* faces, float* alpha, void* workspace, 
     if (B == 0) return GENDR_OK;
     if (!workspace) return GENDR_E_WORKSPACE;
     if ((long)B * nf > 0 && !faces) return GENDR_E_NULL;
-    const int e = gendr_face_setup(faces, faces /* never read in this texture mode */, workspace, B, nf, kSilT, p, stream);
+    const int e = face_setup_impl(faces, faces /* never read in this texture mode */, workspace, B, nf, kSilT, p, stream, true);
     if (e != GENDR_OK) return e;
     if (target && hipMemsetAsync(iou_sums, 0, (size_t)B * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return GENDR_E_LAUNCH;
     RenderArgs a;
@@ -522,7 +541,7 @@ int gendr_silhouette_forward(const float* faces, float* alpha, void* workspace, 
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm, true);
     a.resident_q = resident_per_queue(k.fwd);
-    hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, true))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -549,7 +568,7 @@ int gendr_silhouette_backward(const float* alpha, const void* workspace, const f
     if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, kSilT, p, true, stream);
     const KernelEntry& k = pick_kernel(p, texm, true);
     a.resident_q = resident_per_queue(k.bwd);
-    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, true))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -654,6 +673,13 @@ int gendr_face_info(const float* faces, float* faces_info, int B, int nf, void* 
 int gendr_face_setup(const float* faces, const float* textures, void* workspace,
                      int B, int nf, int T, const gendr_params* p, void* stream)
 {
+    return face_setup_impl(faces, textures, workspace, B, nf, T, p, stream, false);
+}
+
+// `silhouette`: the alpha-only render kernels follow (their occupancy sets the budget of the sub-tile split)
+static int face_setup_impl(const float* faces, const float* textures, void* workspace,
+                           int B, int nf, int T, const gendr_params* p, void* stream, bool silhouette)
+{
     const int v = gendr_validate(p, B, nf, T);
     if (v != GENDR_OK) return v;
     const long total = (long)B * nf;
@@ -723,7 +749,7 @@ int gendr_face_setup(const float* faces, const float* textures, void* workspace,
     if (e != GENDR_OK) return e;
     // heavy tiles first: the render kernels walk the sorted copy of the queue records
     if (w.ordered) {
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderThreads), 0, s, a);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderThreads), 0, s, a, split_budget(p, texm, silhouette));
         return check_launch();
     }
     return GENDR_OK;
@@ -746,7 +772,7 @@ int gendr_forward(const float* faces, const float* textures, float* rgba, float*
     a.aux = aggrs_info;
     const KernelEntry& k = pick_kernel(p, texm);
     a.resident_q = resident_per_queue(k.fwd);
-    hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, false))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -773,7 +799,7 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, T, p, false, stream);
     const KernelEntry& k = pick_kernel(p, texm);
     a.resident_q = resident_per_queue(k.bwd);
-    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks)), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, false))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

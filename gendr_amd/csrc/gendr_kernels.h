@@ -240,7 +240,7 @@ struct __attribute__((aligned(16))) CoverEnt { int fn; int npix; unsigned lo, hi
 // NaN; the depth test :810 / :994 is repeated by backward, which needs the depth anyway).  Backward evaluates one edge with point_to_face_edge() instead of the whole search -- the same
 // float operations on the same operands for that edge, so every value downstream is bit for bit the forward kernel's.
 // A tile's batches are windows of 64 consecutive codes of its pair list, so batch k is the same set of pairs in both
-// kernels as long as neither splits the tile among several waves (walk_split_log2); the forward kernel says so per queue
+// kernels as long as neither splits the tile among several waves (see TileWalk: both use the same grades); the forward kernel says so per queue
 // in the control block (kCtlHintFlag), and face_setup_kernel clears that word with the rest of the block on every call,
 // so hints of an earlier call are never taken for this one's.  A tile has at most as many batches as entries (an entry
 // holds 1..64 pairs), hence the parallel indexing.
@@ -251,8 +251,8 @@ constexpr int kHintDead = 3;
 // takes NaN or infinite candidates on a degenerate face -- backward then repeats the whole search for that queue)
 constexpr int kCtlHintFlag = 1;
 // control[x * kCtlStride + kCtlLive]: (order_tiles_kernel) the tiles of queue x with a non-empty coverage list; they come first
-// in the heavy-first copy of the queue records
-constexpr int kCtlLive = 2;
+// in the heavy-first copy of the queue records (kCtlLive + 1..3: the split grades, see kCtlGrade)
+constexpr int kCtlLive = 4;
 
 __device__ __forceinline__ long queue_begin(int x, long n_tiles) { return ((long)x * n_tiles) >> 3; }
 // the x with queue_begin(x) <= g < queue_begin(x + 1)
@@ -638,24 +638,31 @@ struct TileCtx {
 // The render kernels are launched with a quarter of the waves it would take to give every tile of the batch its
 // own: wave r of XCD x renders entries r, r + stride, ... of queue x.  In the usual scene (at most a quarter of the
 // tiles list a face) that is one tile per wave and no wave is launched in vain.
-struct TileWalk { long qbase, qend; int total, live, empties, rank, next, stride, split_log2, hint_flag; };
+struct TileWalk { long qbase, qend; int total, live, empties, rank, next, stride, hint_flag; int g8, g4, g2, items; };
 
-// Sub-tile split of the render kernels.  The latency of a launch is the latency of one wave on the heaviest tile (ten
-// batches at the headline scene); when a queue lists fewer tiles than the chip holds waves for it at once (resident_q, from
-// the occupancy of the kernel) -- small batches: the per-GPU share of a strong-scaling run -- every listed tile is rendered
-// by 2, 4 or 8 waves, each taking 4, 2 or 1 of its 8 pixel rows (more work items than resident waves only adds a second
-// generation of waves: measured at batch 16 and 32, slower).  A wave
-// keeps only the bits of its rows in the coverage masks, so its pair list, its batches and its time shrink by the split
-// (the entries are read once per wave, which is cheap; forward keeps every pixel's ascending face order, since a pixel
-// belongs to exactly one wave).
-#ifndef GENDR_SPLIT_MAX_LOG2
-#define GENDR_SPLIT_MAX_LOG2 3
-#endif
-__device__ __forceinline__ int walk_split_log2(const TileWalk& w, int resident_q)
+// Graded sub-tile split of the render kernels (round 4; round 3 split every tile of a queue alike).  The latency of a launch is
+// the latency of one wave on the heaviest tile (ten batches at the headline scene); when a queue lists fewer tiles than the
+// chip holds waves for it at once -- small batches: the per-GPU share of a strong-scaling run -- the HEAVY tiles are rendered
+// by 8, 4 or 2 waves, each taking 1, 2 or 4 of the tile's 8 pixel rows.  order_tiles_kernel, which sorts the queue records by
+// weight class anyway, picks the smallest piece size T (a multiple of 32 pairs, at least 64 = one batch) for which
+//     tiles + #(pairs > T) + 2 #(pairs > 2 T) + 4 #(pairs > 4 T)   <=   the waves the chip holds for the queue
+// (more work items than resident waves only add a second generation of waves: measured in round 3, slower) and leaves the
+// numbers g8, g4, g2 of tiles split 8-, 4- and 2-fold in the control block; the sorted records put those tiles first, so work
+// item i of the queue maps to (tile, rows) with three compares.  A wave keeps only the bits of its rows in the coverage masks,
+// so its pair list, its batches and its time shrink by the split (the entries are read once per wave, which is cheap; forward
+// keeps every pixel's ascending face order, since a pixel belongs to exactly one wave).  Both render kernels use the same
+// grades -- the forward kernel's pair hints describe the batches of UNSPLIT tiles, and backward takes them for exactly those.
+constexpr int kCtlGrade = 5;          // control[x * kCtlStride + kCtlGrade + 0..2] = g8, g4, g2 of queue x (order_tiles_kernel)
+// work item i of the queue -> index of its record in the sorted copy, log2 of the tile's split, the piece
+__device__ __forceinline__ int walk_item(const TileWalk& w, int i, int& sl, int& sub)
 {
-    int s = 0;
-    while (s < GENDR_SPLIT_MAX_LOG2 && ((long)w.live << (s + 1)) <= (long)min(w.stride, resident_q + (resident_q >> 2))) s++;
-    return s;
+    if (i < 8 * w.g8) { sl = 3; sub = i & 7; return i >> 3; }
+    i -= 8 * w.g8;
+    if (i < 4 * w.g4) { sl = 2; sub = i & 3; return w.g8 + (i >> 2); }
+    i -= 4 * w.g4;
+    if (i < 2 * w.g2) { sl = 1; sub = i & 1; return w.g8 + w.g4 + (i >> 1); }
+    sl = 0; sub = 0;
+    return w.g8 + w.g4 + w.g2 + (i - 2 * w.g2);
 }
 // pixel lanes (bits) of sub-tile `sub` of 1 << split_log2: whole rows of 8 pixels
 __device__ __forceinline__ unsigned long long sub_tile_mask(int split_log2, int sub)
@@ -678,7 +685,12 @@ __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int 
     w.stride = (int)(gridDim.x >> 3) * waves_per_block;
     w.rank = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * waves_per_block + (int)(threadIdx.x >> 6));
     w.next = w.rank;
-    w.split_log2 = 0;
+    w.g8 = w.g4 = w.g2 = 0;
+    if (a.tile_info != a.tile_info_raw) {
+        const i4v g = *(const GENDR_CONST_AS i4v*)(a.control + xcd * kCtlStride + kCtlGrade - 1);      // (live, g8, g4, g2): one scalar load
+        w.g8 = g.y; w.g4 = g.z; w.g2 = g.w;
+    }
+    w.items = w.live + 7 * w.g8 + 3 * w.g4 + w.g2;
 }
 
 __device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int tile)
@@ -1535,7 +1547,7 @@ __device__ __forceinline__ int order_class(const int4& rec)
     return min((rec.w >> 5) + 1, kOrderClasses - 1);
 }
 
-__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const RenderArgs a)
+__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const RenderArgs a, int budget)
 {
     __shared__ int s_count[kOrderClasses], s_cursor[kOrderClasses];
     const int x = blockIdx.x;
@@ -1552,7 +1564,23 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
         // class 0 = tiles whose coverage list came out EMPTY (every face the binning kernel listed for them was dropped by the
         // exact tests -- the tiles of an image that only a face with a loose cull box reaches): they end up behind all others,
         // and the render kernels treat them as unlisted (kCtlLive = the number of tiles before them)
-        a.control[x * kCtlStride + kCtlLive] = n - s_count[0];
+        const int live = n - s_count[0];
+        a.control[x * kCtlStride + kCtlLive] = live;
+        // split grades (see TileWalk): class c >= 1 holds the tiles of 32 (c - 1) .. 32 c - 1 pairs; a tile is split 2-, 4-, 8-fold if
+        // its class exceeds tc, 2 tc, 4 tc, with the smallest tc >= 2 (pieces of 64 pairs: one batch) whose work items fit `budget`
+        int g8 = 0, g4 = 0, g2 = 0;
+        if (live > 0 && live < budget) {
+            int above[kOrderClasses + 1];                    // above[c] = tiles of a class > c
+            above[kOrderClasses] = 0;
+            for (int c = kOrderClasses - 1; c >= 0; c--) above[c] = above[c + 1] + (c + 1 < kOrderClasses ? s_count[c + 1] : 0);
+            for (int tc = 2; tc < kOrderClasses; tc++) {
+                const int n2 = above[tc], n4 = above[min(2 * tc, kOrderClasses)], n8 = above[min(4 * tc, kOrderClasses)];
+                if (live + n2 + 2 * n4 + 4 * n8 <= budget) { g8 = n8; g4 = n4 - n8; g2 = n2 - n4; break; }
+            }
+        }
+        a.control[x * kCtlStride + kCtlGrade] = g8;
+        a.control[x * kCtlStride + kCtlGrade + 1] = g4;
+        a.control[x * kCtlStride + kCtlGrade + 2] = g2;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kOrderThreads) {
@@ -1571,7 +1599,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
 //     tables and split decisions: ~45 instructions per entry, and per tile that was as much as a batch of pair math);
 //   * entries are appended until at least kFillCodes are listed; the full batches run -- from ONE call site, so that the
 //     caller's phase B is compiled once -- and the remainder (< 64 codes) moves to the front of the buffer;
-//   * `pixels` restricts the list to the pixel rows this wave renders (sub-tile split, see walk_split_log2);
+//   * `pixels` restricts the list to the pixel rows this wave renders (sub-tile split, see TileWalk);
 //   * a tile without a slice of the entry pool (off < 0: the pool is exhausted, e.g. a heavy-tailed distribution lists
 //     every face in every tile) produces its entries here instead, up to 64 at a time: ALL faces of the image are walked
 //     with the face's first record stage in SGPRs (scalar loads) and every lane applies the exact per-pixel tests
@@ -1742,16 +1770,17 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     for (int r = tw.live + tw.rank; r < tw.total; r += tw.stride)
         fill_tile(__builtin_amdgcn_readfirstlane(a.tile_info[tw.qbase + r].x));
 #endif
-    tw.split_log2 = walk_split_log2(tw, a.resident_q);
-    // pair hints for backward (PairHints): written while no tile of the queue is split among several waves
-    const bool hints_q = a.hints != nullptr && tw.split_log2 == 0;
+    // pair hints for backward (PairHints): written for the tiles that are not split among several waves
+    const bool hints_q = a.hints != nullptr;
     if (hints_q && tw.rank == 0 && (threadIdx.x & 63) == 0) atomicOr(a.control + (blockIdx.x & 7) * kCtlStride + kCtlHintFlag, 1);
-    for (; tw.next < (tw.live << tw.split_log2); tw.next += tw.stride) {
+    for (; tw.next < tw.items; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
-    const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
-    PairHints* hint_slot = (hints_q && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's slot (a tile without a slice of the entry pool has none)
+    int split_log2, sub;
+    const int slot_i = walk_item(tw, tw.next, split_log2, sub);
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + slot_i));   // (tile, first entry, entries, pairs): scalar load
+    const unsigned long long my_rows = sub_tile_mask(split_log2, sub);
+    PairHints* hint_slot = (hints_q && split_log2 == 0 && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's slot (a tile without a slice of the entry pool has none)
     TileCtx t;
     tile_setup(t, a, ti.x);
     t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels this wave renders
@@ -2207,17 +2236,19 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     walk_init(tw, a, WAVES);
     GENDR_T(0);                                   // 0: wave start-up (queue lengths)
     GENDR_STAMP(1);
-    tw.split_log2 = walk_split_log2(tw, a.resident_q);
-    // the forward kernel's pair hints hold for this queue if it rendered the queue unsplit (and met no pair a hint cannot
-    // describe) and this kernel does not split either: batch k of a tile is then the same 64 pairs in both
-    const bool hinted_q = a.hints != nullptr && tw.hint_flag == 1 && tw.split_log2 == 0;
-    for (; tw.next < (tw.live << tw.split_log2); tw.next += tw.stride) {
+    // the forward kernel's pair hints hold for the tiles of this queue that are rendered unsplit (the same tiles in both kernels:
+    // the grades come from order_tiles_kernel) unless it met a pair a hint cannot describe: batch k of such a tile is the same
+    // 64 pairs in both
+    const bool hinted_q = a.hints != nullptr && tw.hint_flag == 1;
+    for (; tw.next < tw.items; tw.next += tw.stride) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + (tw.next >> tw.split_log2)));   // (tile, first entry, entries, pairs): scalar load
+    int split_log2, sub;
+    const int slot_i = walk_item(tw, tw.next, split_log2, sub);
+    const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + slot_i));   // (tile, first entry, entries, pairs): scalar load
     if (ti.y >= 0 && ti.z == 0) continue;                       // an empty coverage list (no heavy-first copy: such tiles are not sorted out)
-    const unsigned long long my_rows = sub_tile_mask(tw.split_log2, tw.next & ((1 << tw.split_log2) - 1));
-    const PairHints* hint_slot = (hinted_q && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's hints
+    const unsigned long long my_rows = sub_tile_mask(split_log2, sub);
+    const PairHints* hint_slot = (hinted_q && split_log2 == 0 && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's hints
     if (hint_slot && ti.w <= 4 * 64) {
         // a tile whose few batches hold no pair with a gradient is done before its pixel inputs are fetched (an image with a
         // face seen edge-on lists that face -- no error bound, 64 dead pairs -- in every one of its tiles)
