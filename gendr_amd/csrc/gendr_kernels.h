@@ -154,6 +154,14 @@ __device__ __forceinline__ void load_record(float* dst, RecPtr r)
     }
 }
 
+// a wave-uniform record address as a scalar-register pointer (the compiler cannot always prove the uniformity itself)
+__device__ __forceinline__ RecPtr uniform_rec_ptr(const float* p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<RecPtr>(((unsigned long long)hi << 32) | lo);
+}
+
 // reciprocal of a per-face divisor in two consecutive floats of the face record (see div_by() in gendr_math.h): the
 // correctly rounded double; fast build: its float rounding in the first of the two
 __device__ __forceinline__ rcp_t rec_rcp(const float* r, int k)
@@ -1607,8 +1615,31 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
 constexpr int kChunkBatches = 4;
 constexpr int kFillCodes = kChunkBatches * 64, kCodeCap = kFillCodes + 64;
 
-template <int REC, typename Body>
-__device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCtx& t, int off, int cnt, unsigned long long pixels, int* s_code, Body body)
+// Dense entries (round 4): an entry whose mask holds ALL 64 pixels of the tile -- the rule wherever a distribution's tail
+// reaches tens of pixels (BASELINE config 4: logistic, 35 pixels; the reference's opt_shape.py at 64^2) -- is not turned into
+// codes at all: `dense(face)` runs it with lane = pixel, the face's record in scalar registers (one s_load stream instead of
+// 64 per-lane gathers; the closest-point search, CDF, depth and colour on scalar operands) and folds the result straight into
+// the pixel's registers -- no code list, no per-pixel pair sets, no round trip through LDS.  The codes listed BEFORE it are
+// flushed first (their faces come first in every pixel's fold order), as a last partial batch if need be.  Compiled into the
+// kernels of long-tailed distributions only (dense_path<DIST>()): the others never meet such entries often enough to pay for
+// the registers.
+template <int DIST> __host__ __device__ constexpr bool dense_path()
+{
+    return DIST < 0 || DIST == kLogistic;      // the runtime-dispatch kernels, and BASELINE config 4's
+}
+
+#ifndef GENDR_PIXEL_MODE_AVG
+#define GENDR_PIXEL_MODE_AVG 36
+#endif
+constexpr int kPixelModeAvg = GENDR_PIXEL_MODE_AVG;
+// (tile, first entry, entries, pairs) of an unsplit tile with a slice of the entry pool -> rendered in pixel mode?
+__device__ __forceinline__ bool tile_in_pixel_mode(const i4v& ti, int split_log2)
+{
+    return split_log2 == 0 && ti.y >= 0 && ti.z > 0 && ti.w >= kPixelModeAvg * ti.z;
+}
+
+template <int REC, bool DENSE, typename Body, typename DenseBody>
+__device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCtx& t, int off, int cnt, unsigned long long pixels, bool pixel_mode, int* s_code, Body body, DenseBody dense)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1620,10 +1651,27 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
 
     int e0 = 0, n = 0, j = 0;
     int4 e = make_int4(0, 0, 0, 0);
+    // PIXEL MODE: a tile whose entries hold kPixelModeAvg pixels and more on average (the queue record knows: pairs / entries)
+    // is rendered entry by entry with lane = pixel throughout -- every entry takes the dense path under its own pixel mask, no
+    // code list, no batches: at 54 of 64 pixels per entry (BASELINE config 4) a step of ~200 instructions for one face beats
+    // 54 / 64 of a batch of ~450, and nothing has to be flushed.
+    if (DENSE && pixel_mode) {
+        for (; e0 < cnt; e0 += 64) {
+            n = min(64, cnt - e0);
+            if (lane < n) e = ents[e0 + lane];
+            for (j = 0; j < n; j++) {
+                const int fn = __builtin_amdgcn_readlane(e.x, j);
+                const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j);
+                dense(fn, m);
+            }
+        }
+        return;
+    }
     int npairs = 0;                                  // codes in s_code[0, npairs)
+    int dense_fn = -1;                               // a full-tile entry waiting behind the codes listed so far
     bool done = false;
     for (;;) {
-        // ---- fill: append entries until kFillCodes are listed or the tile's entries are used up
+        // ---- fill: append entries until kFillCodes are listed, a dense entry turns up or the tile's entries are used up
         while (!done && npairs < kFillCodes) {
             if (j == n) {
                 // next group of up to 64 entries into lane-indexed registers
@@ -1650,14 +1698,24 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
             const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j))
                                          & pixels;              // this wave's rows of the tile, see sub_tile_mask
             j++;
+            if (DENSE && m == ~0ull) { dense_fn = fn; break; }
             if ((m >> lane) & 1ull) s_code[npairs + __popcll(m & lt)] = (fn << 6) | lane;
             npairs += __popcll(m);
         }
-        // ---- drain: the full batches, and at the end of the tile the partial one
-        const int nb = done ? (npairs + 63) >> 6 : npairs >> 6;
-        if (nb == 0) break;
-        __builtin_amdgcn_wave_barrier();
-        for (int k = 0; k < nb; k++) body(k << 6, min(64, npairs - (k << 6)));
+        // ---- drain: the full batches; at the end of the tile, or ahead of a dense entry, the partial one as well
+        const bool flush = done || dense_fn >= 0;
+        const int nb = flush ? (npairs + 63) >> 6 : npairs >> 6;
+        if (nb > 0) {
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < nb; k++) body(k << 6, min(64, npairs - (k << 6)));
+        }
+        if (DENSE && dense_fn >= 0) {
+            __builtin_amdgcn_wave_barrier();
+            dense(dense_fn, ~0ull);
+            dense_fn = -1;
+            npairs = 0;
+            continue;
+        }
         if (done) break;
         const int rem = npairs - (nb << 6);
         __builtin_amdgcn_wave_barrier();
@@ -1738,8 +1796,10 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         for (int it = 0; it < 16; it++) p4[(long)it * a.is] = v4;           // 4 rows further = is float4s further
     };
     const bool wide_ok = !a.p.background_from_buffer && ((reinterpret_cast<unsigned long long>(a.rgba) | (kSil ? 0ull : reinterpret_cast<unsigned long long>(a.aux))) & 15ull) == 0ull;
-    for (int r = tw.rank; r < tw.empties; r += tw.stride) {
-        const int tile = __builtin_amdgcn_readfirstlane(a.tile_list[tw.qend - 1 - r]);
+    // (... and the listed tiles whose coverage list came out empty -- behind the live ones in the heavy-first copy: same loop, so
+    // that fill_tile is inlined once)
+    for (int r = tw.rank; r < tw.empties + (tw.total - tw.live); r += tw.stride) {
+        const int tile = __builtin_amdgcn_readfirstlane(r < tw.empties ? a.tile_list[tw.qend - 1 - r] : a.tile_info[tw.qbase + tw.live + (r - tw.empties)].x);
         // a negative entry is an empty super-tile (see bin_faces_kernel): tiles g0 + 8 rows of 8
         const int g0 = tile < 0 ? -tile - 1 : tile;
         if (tile >= 0 || !wide_ok) {
@@ -1765,11 +1825,6 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     }
 #endif
 
-#if GENDR_ABLATE != 5
-    // listed tiles whose coverage list came out empty (behind the live ones in the heavy-first copy): background as well
-    for (int r = tw.live + tw.rank; r < tw.total; r += tw.stride)
-        fill_tile(__builtin_amdgcn_readfirstlane(a.tile_info[tw.qbase + r].x));
-#endif
     // pair hints for backward (PairHints): written for the tiles that are not split among several waves
     const bool hints_q = a.hints != nullptr;
     if (hints_q && tw.rank == 0 && (threadIdx.x & 63) == 0) atomicOr(a.control + (blockIdx.x & 7) * kCtlStride + kCtlHintFlag, 1);
@@ -1780,7 +1835,8 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const int slot_i = walk_item(tw, tw.next, split_log2, sub);
     const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + slot_i));   // (tile, first entry, entries, pairs): scalar load
     const unsigned long long my_rows = sub_tile_mask(split_log2, sub);
-    PairHints* hint_slot = (hints_q && split_log2 == 0 && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's slot (a tile without a slice of the entry pool has none)
+    const bool pixel_mode = dense_path<DIST>() && tile_in_pixel_mode(ti, split_log2);      // (no batches, hence no hints: the same decision in backward)
+    PairHints* hint_slot = (hints_q && split_log2 == 0 && ti.y >= 0 && !pixel_mode) ? a.hints + ti.y : nullptr;   // next batch's slot (a tile without a slice of the entry pool has none)
     TileCtx t;
     tile_setup(t, a, ti.x);
     t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels this wave renders
@@ -1801,6 +1857,43 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     int face_min = -1;
 
     const float* recs_g = a.records + (long)t.b * a.nf * REC;
+
+    // the fold of one evaluated pair into its pixel's state (lane = pixel): kernel.cu:791-838
+    auto fold = [&](const FwdRes& res) __attribute__((always_inline)) {
+        const int fn = res.fn;
+        if (!(res.flags & kFlagContrib)) return;
+        // alpha, kernel.cu:791-803
+        if (alpha_func == kAlphaHard) {
+            if ((double)res.frag > 0.5) alpha = 1.f;
+        } else if constexpr (ALPHA > 0) {
+            alpha = TConorm<(ALPHA > 0 ? ALPHA : 1)>::fold(alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
+        } else if constexpr (ALPHA == -2) {
+            alpha = tconorm_fold_light_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
+        } else {
+            alpha = tconorm_fold_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
+        }
+        if constexpr (kSil) return;
+        if (!(res.flags & kFlagRgb)) return;
+        if (!rgb_soft) {                                                     // :815-822
+            if (res.z < depth_min) {
+                depth_min = res.z;
+                face_min = fn;
+                col[0] = res.c0; col[1] = res.c1; col[2] = res.c2;
+            }
+        } else {                                                             // :824-838
+            const float zn = res.z;
+            // exp_delta_zp and exp_z of :827-832: one of the two is exp(0) == 1 exactly
+            const bool deeper = zn > smax;
+            const float e = exp_f(div_by(deeper ? smax - zn : zn - smax, GENDR_R_GAMMA(a)));
+            const float edz = deeper ? e : 1.f;
+            const float ez = deeper ? 1.f : e;
+            if (deeper) smax = zn;
+            ssum = edz * ssum + ez * res.frag;
+            col[0] = edz * col[0] + ez * res.frag * res.c0;
+            col[1] = edz * col[1] + ez * res.frag * res.c1;
+            col[2] = edz * col[2] + ez * res.frag * res.c2;
+        }
+    };
 
     auto run_batch = [&](int base, int np) __attribute__((always_inline)) {
 #if GENDR_ABLATE == 1
@@ -1874,46 +1967,61 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         alpha += s_res[wave][lane].frag; return;
 #endif
         // ---- phase C: every pixel folds its own pairs; their list positions ascend with the face index
-        for (unsigned long long todo = s_mask[wave][lane]; todo; todo &= todo - 1) {
-            const FwdRes res = s_res[wave][__builtin_ctzll(todo)];
-            const int fn = res.fn;
-            if (!(res.flags & kFlagContrib)) continue;
-            // alpha, kernel.cu:791-803
-            if (alpha_func == kAlphaHard) {
-                if ((double)res.frag > 0.5) alpha = 1.f;
-            } else if constexpr (ALPHA > 0) {
-                alpha = TConorm<(ALPHA > 0 ? ALPHA : 1)>::fold(alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
-            } else if constexpr (ALPHA == -2) {
-                alpha = tconorm_fold_light_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
-            } else {
-                alpha = tconorm_fold_rt(alpha_func, alpha, res.frag, a.p.aggr_alpha_t_conorm_p);
-            }
-            if constexpr (kSil) continue;
-            if (!(res.flags & kFlagRgb)) continue;
-            if (!rgb_soft) {                                                     // :815-822
-                if (res.z < depth_min) {
-                    depth_min = res.z;
-                    face_min = fn;
-                    col[0] = res.c0; col[1] = res.c1; col[2] = res.c2;
-                }
-            } else {                                                             // :824-838
-                const float zn = res.z;
-                // exp_delta_zp and exp_z of :827-832: one of the two is exp(0) == 1 exactly
-                const bool deeper = zn > smax;
-                const float e = exp_f(div_by(deeper ? smax - zn : zn - smax, GENDR_R_GAMMA(a)));
-                const float edz = deeper ? e : 1.f;
-                const float ez = deeper ? 1.f : e;
-                if (deeper) smax = zn;
-                ssum = edz * ssum + ez * res.frag;
-                col[0] = edz * col[0] + ez * res.frag * res.c0;
-                col[1] = edz * col[1] + ez * res.frag * res.c1;
-                col[2] = edz * col[2] + ez * res.frag * res.c2;
-            }
-        }
+        for (unsigned long long todo = s_mask[wave][lane]; todo; todo &= todo - 1) fold(s_res[wave][__builtin_ctzll(todo)]);
         __builtin_amdgcn_wave_barrier();
     };
 
-    for_each_batch<REC>(a, t, ti.y, ti.z, my_rows, s_code[wave], run_batch);
+    // A dense entry (see for_each_batch): face `fn` reaches all 64 pixels of the tile.  lane = pixel, the record in scalar
+    // registers, the same pair functions on the same operands as phase B, and the fold in place.
+    auto run_dense = [&](int fn, unsigned long long mask) __attribute__((always_inline)) {
+        if constexpr (dense_path<DIST>()) {
+            const long face_lin = (long)t.b * a.nf + fn;
+            const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
+            // the record arrives by scalar loads, stage by stage: a stage's floats are requested when the previous stage has been
+            // consumed, so that only one stage occupies scalar registers at a time (the kernel has few to spare: the whole record
+            // at once was spilled lane by lane)
+            float r[REC];
+            RecPtr rs = uniform_rec_ptr(recs_g + (long)fn * REC);
+            load_record<4 * kGatherW0, 4 * kGatherW1>(r, rs);
+            Pair q;
+            barycentrics(q, r, t.xp, t.yp);
+            asm volatile("" : "+s"(rs) : "v"(q.w0), "v"(q.w1), "v"(q.w2));
+            load_record<4 * kGatherA0, 4 * kGatherA1>(r, rs);
+            FwdRes res;
+            res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fn = fn; res.pad1 = 0;
+            bool contributes = false;
+            q.frag = 0.f;
+            if (mine) contributes = soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
+            if constexpr (!kSil) {
+                asm volatile("" : "+s"(rs) : "v"(q.frag));
+                load_record<4 * kGatherB0, REC>(r, rs);
+            }
+            if (contributes) {
+                res.flags = kFlagContrib;
+                res.frag = q.frag;
+                if constexpr (!kSil) {
+                    float wc[3];
+                    const float zp = clip_and_depth(q, r, wc);
+                    if (!(zp < a.p.near_ || zp > a.p.far_)) {                         // :810
+                        res.flags |= kFlagDepthOk;
+                        const bool front = (__float_as_int(r[kRecBits]) & kBitFront) != 0;
+                        const bool eligible = rgb_soft ? (front || a.p.double_side)                         // :825
+                                                       : (inside_closed(q) && (a.p.double_side || front));  // :816
+                        if (eligible) {
+                            res.flags |= kFlagRgb;
+                            res.z = rgb_soft ? div_by(a.p.far_ - zp, GENDR_R_ZRANGE(a)) : zp;   // zp_norm (:826) or zp
+                            float cc[3]; int own;
+                            sample_colour<TEXM>(cc, own, wc, r, a, face_lin);
+                            res.c0 = cc[0]; res.c1 = cc[1]; res.c2 = cc[2];
+                        }
+                    }
+                }
+            }
+            fold(res);
+        }
+    };
+
+    for_each_batch<REC, dense_path<DIST>()>(a, t, ti.y, ti.z, my_rows, pixel_mode, s_code[wave], run_batch, run_dense);
 
     if constexpr (kSil) {
         // alpha plane, and the tile's share of the fused IoU sums (opt_shape.py:20-24: intersect = sum(a t),
@@ -1997,10 +2105,10 @@ struct PixIn {             // 48 bytes: per-pixel inputs of the backward pass, k
     float g[4], out[4], ssum, smax, xp, yp;
 };
 
-template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, bool PRELOADED = false>
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int PRELOADED = 0>
 __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistParams& dp, const float* rg, const PixIn& px, int fn, long face_lin,
                                               float (&gv)[9], float (&gt)[GradTex<TEXM>::n], int& tex_own, float (&tex_val)[3],
-                                              bool hinted = false, bool e0 = false, bool e1 = false)
+                                              bool hinted = false, bool e0 = false, bool e1 = false, bool mine = true)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int NT = GradTex<TEXM>::n;
@@ -2009,11 +2117,18 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
-    // PRELOADED: rg is the caller's register copy of the whole record (one face per wavefront: loaded once, not per pair)
+    // PRELOADED 1: rg is the caller's register copy of the whole record (one face per wavefront: loaded once, not per pair);
+    // PRELOADED 2: rg points at the record of a wave-uniform face (a dense entry, see for_each_batch): scalar loads, stage by
+    // stage -- a stage's floats are requested when the previous stage has been consumed, so that only one stage occupies
+    // scalar registers at a time (the kernels have few to spare: the whole record at once was spilled lane by lane)
     float r[REC];
-    if constexpr (PRELOADED) {
+    RecPtr rs = nullptr;
+    if constexpr (PRELOADED == 2) rs = uniform_rec_ptr(rg);
+    if constexpr (PRELOADED == 1) {
 #pragma unroll
         for (int k = 0; k < REC; k++) r[k] = rg[k];
+    } else if constexpr (PRELOADED == 2) {
+        load_record<4 * kGatherW0, 4 * kGatherW1>(r, rs);
     } else {
         gather_record<kGatherW0, kGatherW1>(r, rg);
         gather_record<kGatherA0, kGatherA1>(r, rg);
@@ -2021,17 +2136,27 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
     const float pxp = px.xp, pyp = px.yp;
     Pair q;
     barycentrics(q, r, pxp, pyp);
+    if constexpr (PRELOADED == 2) {
+        asm volatile("" : "+s"(rs) : "v"(q.w0), "v"(q.w1), "v"(q.w2));
+        load_record<4 * kGatherA0, 4 * kGatherA1>(r, rs);
+    }
     // Two stages one after the other, not nested: `live` is narrowed by the first and guards the second, and the
     // partials are defined in the second only (as values that survive a nest of early exits they were
     // re-initialised at every level of it: 58 moves per batch; the empty asm below keeps the compiler from turning
     // the final select back into such a default).
     float C_xy = 0.f, zp = 0.f;
     float wc[3];
-    bool live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp, hinted, e0, e1);
+    bool live = false;
+    q.frag = 0.f;
+    if (mine) live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp, hinted, e0, e1);     // (`mine`: the lane holds a pair at all -- dense entries under a pixel mask)
+    if constexpr (PRELOADED == 2) {
+        asm volatile("" : "+s"(rs) : "v"(q.frag));
+        load_record<4 * kGatherB0, REC>(r, rs);
+    }
     if (live) {
         // alpha only, and this face's depth cannot fail the near / far test (see face_setup_kernel): no depth stage
         const bool need_depth = !(kSil && (__float_as_int(r[kRecBits]) & kBitDepthSafe));
-        if constexpr (!PRELOADED) { if (need_depth) gather_record<kGatherB0, REC / 4>(r, rg); }
+        if constexpr (PRELOADED == 0) { if (need_depth) gather_record<kGatherB0, REC / 4>(r, rg); }
         // alpha partial, kernel.cu:973-987 (hard alpha leaves g[3] unscaled, as the reference does)
         float C_alpha = px.g[3];
         if (alpha_func != kAlphaHard) {
@@ -2248,7 +2373,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + slot_i));   // (tile, first entry, entries, pairs): scalar load
     if (ti.y >= 0 && ti.z == 0) continue;                       // an empty coverage list (no heavy-first copy: such tiles are not sorted out)
     const unsigned long long my_rows = sub_tile_mask(split_log2, sub);
-    const PairHints* hint_slot = (hinted_q && split_log2 == 0 && ti.y >= 0) ? a.hints + ti.y : nullptr;   // next batch's hints
+    const bool pixel_mode = dense_path<DIST>() && tile_in_pixel_mode(ti, split_log2);
+    const PairHints* hint_slot = (hinted_q && split_log2 == 0 && ti.y >= 0 && !pixel_mode) ? a.hints + ti.y : nullptr;   // next batch's hints
     if (hint_slot && ti.w <= 4 * 64) {
         // a tile whose few batches hold no pair with a gradient is done before its pixel inputs are fetched (an image with a
         // face seen edge-on lists that face -- no error bound, 64 dead pairs -- in every one of its tiles)
@@ -2366,7 +2492,56 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         GENDR_T(6);                               // 6: segment sums + atomics issued
     };
 
-    for_each_batch<REC>(a, t, ti.y, ti.z, my_rows, s_code[wave], run_batch);
+    // A dense entry (see for_each_batch): face `fn` reaches all 64 pixels of the tile.  lane = pixel, the record in scalar
+    // registers, backward_pair() as everywhere; the partials of the ONE face are summed by four lanes per component (sixteen
+    // consecutive pairs each, combined inside the quad) and leave as one atomic per component.
+    auto run_dense = [&](int fn, unsigned long long mask) __attribute__((always_inline)) {
+        if constexpr (dense_path<DIST>()) {
+            const long face_lin = (long)t.b * a.nf + fn;
+            const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
+            const PixIn px = s_pix[wave][lane];
+            float gv[9];
+            float gt[NT];
+            int tex_own = -1;
+            float tex_val[3] = {0.f, 0.f, 0.f};
+            const bool live = backward_pair<DIST, ALPHA, RGB, SQ, TEXM, 2>(a, dp, recs_g + (long)fn * REC, px, fn, face_lin, gv, gt, tex_own, tex_val, false, false, false, mine);
+            if constexpr (TEXM == kTexSurfaceN) {
+                if (live && tex_own >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(a.grad_textures + (face_lin * a.T + tex_own) * 3 + k, tex_val[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) asm("" : "+v"(gv[k]));
+#pragma unroll
+            for (int k = 0; k < NG - 9; k++) asm("" : "+v"(gt[k]));
+#pragma unroll
+            for (int k = 0; k < 9; k++) s_val[wave][k * 65 + lane] = live ? gv[k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < NG - 9; k++) s_val[wave][(9 + k) * 65 + lane] = live ? gt[k] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            constexpr int PER = NG <= 16 ? 4 : 2;                // lanes per component (NG = 9, 12: 4; 18: 2)
+            constexpr int LEN = 64 / PER;
+            const int k = lane / PER, seg = lane % PER;
+            float v = 0.f;
+            if (k < NG) {
+                const float* col = &s_val[wave][k * 65 + seg * LEN];
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+                for (int i = 0; i < LEN; i += 4) { v0 += col[i]; v1 += col[i + 1]; v2 += col[i + 2]; v3 += col[i + 3]; }
+                v = (v0 + v1) + (v2 + v3);
+            }
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+            if (PER == 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+            if (k < NG && seg == 0 && v != 0.f) {
+                if (k < 9) unsafeAtomicAdd(a.grad_faces + face_lin * 9 + k, v);
+                else       unsafeAtomicAdd(a.grad_textures + face_lin * (NG - 9) + (k - 9), v);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    for_each_batch<REC, dense_path<DIST>()>(a, t, ti.y, ti.z, my_rows, pixel_mode, s_code[wave], run_batch, run_dense);
     __builtin_amdgcn_wave_barrier();
     GENDR_T(7);                                   // 7: tail of the tile (entry walk after the last batch)
     }   // tile loop
@@ -2507,7 +2682,7 @@ __device__ __forceinline__ void det_rows(const RenderArgs& a, const DistParams& 
         int tex_own = -1;
         float tex_val[3] = {0.f, 0.f, 0.f};
         bool ok = false;
-        if (live) ok = backward_pair<DIST, ALPHA, RGB, SQ, TEXM, true>(a, dp, rec, px, fn, face_lin, gv, gt, tex_own, tex_val);
+        if (live) ok = backward_pair<DIST, ALPHA, RGB, SQ, TEXM, 1>(a, dp, rec, px, fn, face_lin, gv, gt, tex_own, tex_val);
 #pragma unroll
         for (int k = 0; k < 9; k++) asm("" : "+v"(gv[k]));
 #pragma unroll

@@ -1,5 +1,6 @@
-"""Queue lengths, grade counts of the graded split (walk_plan) and pair weights per listed tile, read back from the workspace.
-    python tools/gradestats.py [--config c2] [--batch 8]"""
+"""Queue lengths, grades of the graded sub-tile split (order_tiles_kernel, TileWalk) and pair weights per listed tile, read back
+from the workspace.
+    python tools/gradestats.py [--config c2] [--batch 8] [--size 64] [key=value ...]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -11,11 +12,19 @@ from gendr_amd.functional import renderer as R
 from gendr_amd.synthetic import benchmark_scene
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--config', default='c2'); ap.add_argument('--batch', type=int, default=8)
+ap.add_argument('--config', default='c2'); ap.add_argument('--batch', type=int, default=8); ap.add_argument('--size', type=int, default=0)
+ap.add_argument('opts', nargs='*')
 args = ap.parse_args()
 cfg = B.CONFIGS[args.config]
-Bn, isz = args.batch, cfg['image_size']
+Bn, isz = args.batch, args.size or cfg['image_size']
 opts = dict(cfg['opts']); opts.setdefault('double_side', False)
+for kv in args.opts:
+    k, v = kv.split('=')
+    try:
+        v = float(v) if ('.' in v or 'e' in v) else int(v)
+    except ValueError:
+        pass
+    opts[k] = v
 fv, tex = benchmark_scene(Bn, subdivisions=cfg['subdiv'], texture=cfg['texture'])
 o, extra = parity.split_options(opts)
 p = parity.hip_params(isz, o, extra)
@@ -35,6 +44,7 @@ control = w[len(w) - 24 * 1024 * 4:].view(np.int32)
 for x in range(8):
     n = int(control[x * 1024]); qb = x * tiles // 8
     pw = info[qb:qb + n, 3]
-    print('queue %d: %4d listed, flag %d, grades >=512/256/128: %s | from the records: %d %d %d | pairs max %d, p50 %d'
-          % (x, n, control[x * 1024 + 1], list(control[x * 1024 + 2:x * 1024 + 5]), int((pw >= 512).sum()), int((pw >= 256).sum()), int((pw >= 128).sum()),
-             int(pw.max()) if n else 0, int(np.median(pw)) if n else 0))
+    live, g8, g4, g2 = (int(v) for v in control[x * 1024 + 4:x * 1024 + 8])
+    print('queue %d: %4d listed, %4d live, hint flag %d, split 8/4/2-fold: %d %d %d -> %d work items | pairs per tile max %d, p90 %d, p50 %d, entries p50 %d'
+          % (x, n, live, control[x * 1024 + 1], g8, g4, g2, live + 7 * g8 + 3 * g4 + g2,
+             int(pw.max()) if n else 0, int(np.percentile(pw, 90)) if n else 0, int(np.median(pw)) if n else 0, int(np.median(info[qb:qb + n, 2])) if n else 0))
