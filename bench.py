@@ -703,10 +703,18 @@ def main():
                     if pmc.get('kernel_sha') == _b.source_sha():
                         traffic = pmc.get('hbm_bytes_per_launch', {}).get(dom)
                         valu_busy = pmc.get('valu_busy', {}).get(dom)
-                        source = ('profiles/pmc_%s.json (kernel sources %s): rocprofv3 --pmc passes of this command at the config\'s '
-                                  'single-GPU batch (profiles/run_all.sh); traffic = 2*FETCH_SIZE+WRITE_SIZE, valu_busy = '
-                                  'SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * kernel time * 2.4 GHz); not re-measured in this run'
-                                  % (args.config, pmc['kernel_sha']))
+                        # traffic is quoted PER LAUNCH of this line's batch: the counter passes record the batch they ran at
+                        # (C4 / C5 counters of one batch were set beside the algorithmic bytes of another); a pass at
+                        # another batch is scaled linearly (the traffic is per frame to a few percent) and the line says so
+                        tb = pmc.get('traffic_batch')
+                        scaled = ''
+                        if traffic is not None and tb and tb != B:
+                            traffic = traffic * B / tb
+                            scaled = '; traffic measured at batch %d and scaled to this line\'s %d frames on rank 0' % (tb, B)
+                        source = ('profiles/pmc_%s.json (kernel sources %s): rocprofv3 --pmc passes (profiles/run_all.sh): traffic = '
+                                  '2*FETCH_SIZE+WRITE_SIZE of bench.py at batch %s%s; valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * '
+                                  'GRBM_GUI_ACTIVE of the same launch), tools/kbench.py at batch %s; not re-measured in this run'
+                                  % (args.config, pmc['kernel_sha'], tb, scaled, pmc.get('sq_batch')))
                     else:
                         source = ('profiles/pmc_%s.json was collected on other kernel sources (%s, now %s): traffic and valu_busy withheld'
                                   % (args.config, pmc.get('kernel_sha'), _b.source_sha()))

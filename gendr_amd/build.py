@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
 # sub-expressions) and FMA contraction ON -- what nvcc does to the reference by default (/root/reference/setup.py:10).
 # Gated on the GPU by the spread of the reference's own two builds (tests/test_gpu_fast_variant.py); never the silent
 # default: GENDR_VARIANT=fast or _native.use_variant('fast') select it, bench.py reports it under extra.fast_variant.
-VARIANTS = {"default": [], "exact": ["-DGENDR_EXACT_GRADIENT=1"], "fast": ["-DGENDR_FAST_MATH=1", "-ffp-contract=fast"]}
+VARIANTS = {"default": [], "exact": ["-DGENDR_EXACT_GRADIENT=1"], "fast": ["-DGENDR_FAST_MATH=1", "-ffp-contract=on"]}
 
 
 def lib_path(variant="default"):

@@ -741,6 +741,13 @@ static int face_setup_impl(const float* faces, const float* textures, void* work
 #define GENDR_COVER_GRID_MUL 1
 #endif
     if (w.ent_cap8 == 0) return GENDR_OK;                       // no entry pool: every listed tile takes the render kernels' own walk
+    {
+        // region tags (CoverEnt) pay where entries cover most of a tile -- a cull radius of a tile's width and more -- and only the
+        // kernels with the dense path read them (measured at BASELINE config 2, where neither holds: +5 us in the coverage kernel)
+        const KernelEntry& k = pick_kernel(p, texm, silhouette);
+        const bool dense = k.key.dist < 0 || k.key.dist == kLogistic;           // dense_path<DIST>() of gendr_kernels.h
+        a.want_tags = (dense && cull_r * (float)p->image_size * 0.5f >= (float)kTile) ? 1 : 0;
+    }
     const int cblocks = render_blocks(a.total_blocks) * GENDR_COVER_GRID_MUL;
     if (texm == kTexSurface1)    hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurface1)>, dim3(cblocks), dim3(kThreads), 0, s, a);
     else if (texm == kTexVertex) hipLaunchKernelGGL(cover_kernel<record_floats(kTexVertex)>, dim3(cblocks), dim3(kThreads), 0, s, a);

@@ -239,6 +239,10 @@ constexpr int kBinRec = 16;
 
 // One entry of a tile's coverage list: face index and the ballot of the tile's pixels that pass the exact box / edge
 // tests for it (bit p = pixel lane p).  Written by cover_kernel, read by both render kernels.
+// npix: bits 0..7 the pixels of the mask; bits 8..9 the REGION TAG (round 4): 0 = nothing known; 1, 2, 3 = every pixel of the
+// mask lies outside the face and the closest-point search of kernel.cu:120-142 selects the same edge for all of them (edge
+// tag - 1) -- proven by the coverage kernel from the signs of the three barycentrics over the entry's pixel rows.  The dense /
+// pixel-mode paths of the render kernels then evaluate that one edge with wave-uniform selects (point_to_face_edge()).
 struct __attribute__((aligned(16))) CoverEnt { int fn; int npix; unsigned lo, hi; };
 
 // Pair hints: what the forward kernel found out about the 64 pairs of a batch and the backward kernel would otherwise have to
@@ -303,6 +307,7 @@ struct RenderArgs {
     int4*       loose_box;
     int*        loose_image;
     int         loose_stamp;
+    int         want_tags;      // the coverage kernel works out region tags (CoverEnt): the render kernels that follow have the dense path and the cull radius spans a tile
     int         rec_floats;     // floats per face record (record_floats(texture mode)): for the kernels that are not templated on it
     float       cull_r2;        // (cull radius)^2, rounded up: an outside pixel whose computed squared distance reaches it is dead
     gendr_params p;
@@ -823,12 +828,12 @@ __device__ __forceinline__ bool point_to_face(Pair& q, const float* r, float xp,
 // the corner logic, the very expressions of the two branches above on the very operands (inside: t, 1 - t unclamped,
 // :99-105; outside: clamped, :150-158), so dx, dy, t and with them the fragment are bit for bit the forward kernel's.
 // e0 / e1: the selected edge is 0 / 1 (neither: 2).
-__device__ __forceinline__ void point_to_face_edge(Pair& q, const float* r, bool e0, bool e1)
+__device__ __forceinline__ void point_to_face_edge(Pair& q, const float* r, bool e0, bool e1, bool outside_known = false)
 {
     const float w0 = q.w0, w1 = q.w1, w2 = q.w2;
     const float x0 = r[kRecXY + 0], y0 = r[kRecXY + 1], x1 = r[kRecXY + 2], y1 = r[kRecXY + 3],
                 x2 = r[kRecXY + 4], y2 = r[kRecXY + 5];
-    const bool inside = w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1;
+    const bool inside = !outside_known && w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1;
     const float E00 = r[kRecEdge + 0], E01 = r[kRecEdge + 1], E02 = r[kRecEdge + 2];
     const float E10 = r[kRecEdge + 3], E11 = r[kRecEdge + 4], E12 = r[kRecEdge + 5];
     const float E20 = r[kRecEdge + 6], E21 = r[kRecEdge + 7], E22 = r[kRecEdge + 8];
@@ -875,14 +880,16 @@ __device__ __forceinline__ void barycentrics(Pair& q, const float* r, float xp, 
 // contributes (none of the skips at :769, :784 fires).
 template <int DIST, int SQ>
 __device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp, float yp, const RenderArgs& a, const DistParams& dp,
-                                              bool hinted = false, bool e0 = false, bool e1 = false)
+                                              bool hinted = false, bool e0 = false, bool e1 = false, bool tagged = false)
 {
+    // hinted: the forward kernel recorded the pair's edge AND that it passed the skip tests (pair hints, backward only);
+    // tagged: the coverage kernel proved the edge for every pixel of the entry (region tag) -- the skip tests still apply
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     if (dist == kHeaviside) {
         q.sign = 0.f; q.dx = 0.f; q.dy = 0.f; q.dis = 0.f; q.t0 = q.t1 = q.t2 = 0.f; q.hint = kHintEdge0;
         q.frag = inside_closed(q) ? 1.f : 0.f;                                      // :762-764
     } else {
-        if (hinted) point_to_face_edge(q, r, e0, e1);
+        if (hinted || tagged) point_to_face_edge(q, r, e0, e1, tagged);
         else if (!point_to_face(q, r, xp, yp)) return false;
         float dis = q.dx * q.dx + q.dy * q.dy;                                      // :768
         if (!hinted && q.sign < 0 && dis >= a.thr) return false;                    // :769 (a hinted pair passed it in the forward kernel)
@@ -1435,6 +1442,7 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 float r[kRecStage1];
                 gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
                 unsigned m8 = 0u;
+                unsigned unproven = 0u;                     // region tag: what this lane's row leaves unproven (rows without a pixel: nothing)
                 // The entries only have to be a SUPERSET of the contributing pairs (every pair still meets the reference's own
                 // skip tests in the render kernels).  Along a pixel row each barycentric is linear in the column c = 0..7,
                 // w_k(c) = w_k(0) + c d_k, so the columns that pass all three edge thresholds and the cull box form ONE interval:
@@ -1472,6 +1480,23 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                     const int c_first = max(0, (int)ceilf(fminf(lo, 16.f) - kColSlack));
                     const int c_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(hi, -2.f) + kColSlack));
                     if (!none && c_last >= c_first) m8 = ((2u << c_last) - 1u) & ~((1u << c_first) - 1u);
+                    // Region tag (see CoverEnt): along the row's pixels c_first .. c_last every barycentric is linear, so its sign
+                    // is settled by the two ends -- where both lie beyond a margin of 2^-19 (|a| + |b| + |c|) on the same side (the
+                    // model w_k(0) + c d_k and the value barycentrics() computes for the pixel differ by less than half of that,
+                    // see kSlack above).  Bits 0..2: w_k <= 0 NOT proven for the row; bits 3..5: w_k > 0 NOT proven.  NaN proves
+                    // nothing.
+                    if (m8 && a.want_tags) {
+                        const float cf = (float)c_first, cl = (float)c_last;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const float ak = r[kRecInv + 3 * k], bk = r[kRecInv + 3 * k + 1], ck = r[kRecInv + 3 * k + 2];
+                            const float w = ak * xs[0] + bk * yp_a + ck, dk = ak * pitch;
+                            const float mk = kSlack * (fabsf(ak) + fabsf(bk) + fabsf(ck));
+                            const float wa = w + cf * dk, wb = w + cl * dk;
+                            if (!(fmaxf(wa, wb) <= -mk) || !(wa == wa) || !(wb == wb)) unproven |= 1u << k;
+                            if (!(fminf(wa, wb) >= mk) || !(wa == wa) || !(wb == wb)) unproven |= 8u << k;
+                        }
+                    }
                 }
                 const bool loose_l = has && __float_as_int(r[kRecLoose]) != 0;         // (the eight lanes of a slot hold the same record)
                 if (loose_l) m8 = 0u;
@@ -1506,11 +1531,30 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                     if (lane == l) { v = (unsigned)lm; hi = (unsigned)(lm >> 32); my_pairs += __popcll(lm); }
                 }
                 my_pairs += __popc(m8);
+                // the rows' verdicts OR-ed over the face's eight lanes (as the row masks above), then the decision tree of
+                // kernel.cu:120-142 on the proven signs; a corner region whose obtuse-angle test (:122, :128, :134) would have to be
+                // evaluated per pixel gets no tag
+                unsigned up = quad_or(unproven);
+                up |= (unsigned)__shfl_down((int)up, 4);
+                int tag = 0;
+                if (!loose_l && a.want_tags) {
+                    const int bits = __float_as_int(r[kRecBits]);
+                    const bool n0 = !(up & 1u), n1 = !(up & 2u), n2 = !(up & 4u);          // w_k <= 0 on every pixel
+                    const bool p0 = !(up & 8u), p1 = !(up & 16u), p2 = !(up & 32u);       // w_k > 0 on every pixel
+                    if ((n0 || p0) && (n1 || p1) && (n2 || p2)) {
+                        if (n1 && n2)      tag = (bits & 1) ? 0 : 1;           // v0 = 0
+                        else if (n2 && n0) tag = (bits & 2) ? 0 : 2;           // v0 = 1
+                        else if (n0 && n1) tag = (bits & 4) ? 0 : 3;           // v0 = 2
+                        else if (n0)       tag = 2;                            // v0 = 1
+                        else if (n1)       tag = 3;                            // v0 = 2
+                        else if (n2)       tag = 1;                            // v0 = 0
+                    }
+                }
                 const bool owns = prow == 0 && (v | hi) != 0u;
                 const unsigned long long keep = __ballot(owns);
                 if (owns) {
                     CoverEnt e;
-                    e.fn = fn; e.npix = __popc(v) + __popc(hi); e.lo = v; e.hi = hi;
+                    e.fn = fn; e.npix = (__popc(v) + __popc(hi)) | (tag << 8); e.lo = v; e.hi = hi;
                     out[nout + __popcll(keep & lt)] = e;
                 }
                 nout += __popcll(keep);
@@ -1662,13 +1706,13 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
             for (j = 0; j < n; j++) {
                 const int fn = __builtin_amdgcn_readlane(e.x, j);
                 const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j);
-                dense(fn, m);
+                dense(fn, m, (__builtin_amdgcn_readlane(e.y, j) >> 8) & 3);
             }
         }
         return;
     }
     int npairs = 0;                                  // codes in s_code[0, npairs)
-    int dense_fn = -1;                               // a full-tile entry waiting behind the codes listed so far
+    int dense_fn = -1, dense_tag = 0;                // a full-tile entry waiting behind the codes listed so far (and its region tag)
     bool done = false;
     for (;;) {
         // ---- fill: append entries until kFillCodes are listed, a dense entry turns up or the tile's entries are used up
@@ -1698,7 +1742,7 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
             const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j))
                                          & pixels;              // this wave's rows of the tile, see sub_tile_mask
             j++;
-            if (DENSE && m == ~0ull) { dense_fn = fn; break; }
+            if (DENSE && m == ~0ull) { dense_fn = fn; dense_tag = (__builtin_amdgcn_readlane(e.y, j - 1) >> 8) & 3; break; }
             if ((m >> lane) & 1ull) s_code[npairs + __popcll(m & lt)] = (fn << 6) | lane;
             npairs += __popcll(m);
         }
@@ -1711,7 +1755,7 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
         }
         if (DENSE && dense_fn >= 0) {
             __builtin_amdgcn_wave_barrier();
-            dense(dense_fn, ~0ull);
+            dense(dense_fn, ~0ull, dense_tag);
             dense_fn = -1;
             npairs = 0;
             continue;
@@ -1973,7 +2017,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
 
     // A dense entry (see for_each_batch): face `fn` reaches all 64 pixels of the tile.  lane = pixel, the record in scalar
     // registers, the same pair functions on the same operands as phase B, and the fold in place.
-    auto run_dense = [&](int fn, unsigned long long mask) __attribute__((always_inline)) {
+    auto run_dense = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) {
         if constexpr (dense_path<DIST>()) {
             const long face_lin = (long)t.b * a.nf + fn;
             const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
@@ -1991,7 +2035,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fn = fn; res.pad1 = 0;
             bool contributes = false;
             q.frag = 0.f;
-            if (mine) contributes = soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp);
+            if (mine) contributes = soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp, false, tag == 1, tag == 2, tag != 0);
             if constexpr (!kSil) {
                 asm volatile("" : "+s"(rs) : "v"(q.frag));
                 load_record<4 * kGatherB0, REC>(r, rs);
@@ -2108,7 +2152,7 @@ struct PixIn {             // 48 bytes: per-pixel inputs of the backward pass, k
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM, int PRELOADED = 0>
 __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistParams& dp, const float* rg, const PixIn& px, int fn, long face_lin,
                                               float (&gv)[9], float (&gt)[GradTex<TEXM>::n], int& tex_own, float (&tex_val)[3],
-                                              bool hinted = false, bool e0 = false, bool e1 = false, bool mine = true)
+                                              bool hinted = false, bool e0 = false, bool e1 = false, bool mine = true, bool tagged = false)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr int NT = GradTex<TEXM>::n;
@@ -2148,7 +2192,7 @@ __device__ __forceinline__ bool backward_pair(const RenderArgs& a, const DistPar
     float wc[3];
     bool live = false;
     q.frag = 0.f;
-    if (mine) live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp, hinted, e0, e1);     // (`mine`: the lane holds a pair at all -- dense entries under a pixel mask)
+    if (mine) live = soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp, hinted, e0, e1, tagged);     // (`mine`: the lane holds a pair at all -- dense entries under a pixel mask)
     if constexpr (PRELOADED == 2) {
         asm volatile("" : "+s"(rs) : "v"(q.frag));
         load_record<4 * kGatherB0, REC>(r, rs);
@@ -2495,7 +2539,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     // A dense entry (see for_each_batch): face `fn` reaches all 64 pixels of the tile.  lane = pixel, the record in scalar
     // registers, backward_pair() as everywhere; the partials of the ONE face are summed by four lanes per component (sixteen
     // consecutive pairs each, combined inside the quad) and leave as one atomic per component.
-    auto run_dense = [&](int fn, unsigned long long mask) __attribute__((always_inline)) {
+    auto run_dense = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) {
         if constexpr (dense_path<DIST>()) {
             const long face_lin = (long)t.b * a.nf + fn;
             const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
@@ -2504,7 +2548,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
             float gt[NT];
             int tex_own = -1;
             float tex_val[3] = {0.f, 0.f, 0.f};
-            const bool live = backward_pair<DIST, ALPHA, RGB, SQ, TEXM, 2>(a, dp, recs_g + (long)fn * REC, px, fn, face_lin, gv, gt, tex_own, tex_val, false, false, false, mine);
+            const bool live = backward_pair<DIST, ALPHA, RGB, SQ, TEXM, 2>(a, dp, recs_g + (long)fn * REC, px, fn, face_lin, gv, gt, tex_own, tex_val, false, tag == 1, tag == 2, mine, tag != 0);
             if constexpr (TEXM == kTexSurfaceN) {
                 if (live && tex_own >= 0) {
 #pragma unroll

@@ -9,6 +9,6 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${CFG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $CFG -- \
-    python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $OUT/bench.log 2>&1
 grep '^{' $OUT/bench.log > $OUT/bench.json || true
 ls $OUT

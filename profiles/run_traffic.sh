@@ -8,6 +8,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o t -- \
-      python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline > $OUT/$C.log 2>&1
+      python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $OUT/$C.log 2>&1
 done
 python $GRAFT_REPO_ROOT/tools/traffic_summary.py $OUT $CFG

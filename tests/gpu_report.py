@@ -22,6 +22,7 @@ import numpy as np
 
 import criteria
 import parity
+import pin
 import scenes
 
 FULL = {
@@ -34,6 +35,7 @@ FULL = {
 
 
 VARIANTS = ('default', 'exact')
+FAST = os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gendr_amd', 'libgendr_hip_fast.so'))
 
 
 def one_case(fv, tex, isz, opts, with_cull_check=True, n_jitter=len(criteria.JITTER_MODES)):
@@ -79,6 +81,20 @@ def one_case(fv, tex, isz, opts, with_cull_check=True, n_jitter=len(criteria.JIT
                 aggrs_info_max=float(parity.rel_error(r64['aggrs_info'], o64['aggrs_info']).max()),
                 grad_faces_max=float(parity.rel_error(r64['grad_faces'], o64['grad_faces'], scale=o64['abs_faces'], floor=parity.GRAD_FLOOR).max()),
                 grad_textures_max=float(parity.rel_error(r64['grad_textures'], o64['grad_textures'], scale=o64['abs_textures'], floor=parity.GRAD_FLOOR).max())))
+        # the flat gate of tests/pin.py (1e-5 on every element against the reference's kernels) for the three build variants,
+        # the spread of the reference's own two builds (contraction off / on), and the fast variant against that spread
+        rf = parity.run_reference(fv, tex, isz, opts, grad, np.float32, variant='render_fma')
+        spread = pin.measure(rf, r32, o32['abs_faces'], o32['abs_textures'])
+        flat = {v: pin.measure(hips[v], r32, o32['abs_faces'], o32['abs_textures']) for v in hips}
+        if FAST:
+            hf = parity.run_hip(fv, tex, isz, opts, grad, variant='fast')
+            flat['fast'] = pin.measure(hf, r32, o32['abs_faces'], o32['abs_textures'])
+            br = pin.bracket(hf, r32, rf, o32['abs_faces'], o32['abs_textures'])
+            entry['fast'] = dict(vs_reference=flat['fast'], outside_spread=pin.spread_failures('', flat['fast'], spread),
+                                 elementwise_bracket={k: dict(violations=b['violations'], n=b['n'], worst_over_bound=b['worst_over_bound']) for k, b in br.items()})
+        entry['reference_kernels']['flat_1e5'] = {v: dict(meets=not pin.exceptions_of(m), max={k: x['max'] for k, x in m.items()},
+                                                          frac_gt_1e5={k: x['frac'] for k, x in m.items()}) for v, m in flat.items()}
+        entry['reference_kernels']['reference_fma_vs_nofma'] = {k: {q: x[q] for q in ('max', 'p50', 'p99', 'p999', 'frac')} for k, x in spread.items()}
     if with_cull_check:
         h, h2 = hips['default'], parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
         entry['cull_identical'] = bool(all(np.array_equal(h[k], h2[k], equal_nan=True) for k in ('rgba', 'aggrs_info')))
@@ -105,7 +121,7 @@ def short(name, entry):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
     try:
         head = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
@@ -156,10 +172,28 @@ def main():
             faces_info_identical=sum(1 for r in pinned if r['restatement_vs_reference_f32']['faces_info_identical'] and r['restatement_vs_reference_f64']['faces_info_identical']),
             restatement_f64_rgba_max_without_cauchy=max(r['restatement_vs_reference_f64']['rgba_max'] for r in non_cauchy),
             restatement_f64_grad_faces_max_without_cauchy=max(r['restatement_vs_reference_f64']['grad_faces_max'] for r in non_cauchy))
+        summ['reference_kernels']['flat_1e5_met'] = {v: sum(1 for r in pinned if r['flat_1e5'].get(v, {}).get('meets')) for v in ('default', 'exact', 'fast')
+                                                     if any(v in r['flat_1e5'] for r in pinned)}
+        fast = [c['fast'] for c in cases if 'fast' in c]
+        if fast:
+            summ['fast_variant'] = dict(
+                cases=len(fast), inside_reference_spread=sum(1 for f in fast if not f['outside_spread']),
+                with_elements_outside_elementwise_bracket=sum(1 for f in fast if any(b['violations'] for b in f['elementwise_bracket'].values())),
+                rule='quantiles p50..p99.9 of the error against the reference kernels within %gx the same quantiles of the spread of the '
+                     'reference\'s two builds (floor %g), tests/pin.py' % (pin.SPREAD_K, pin.SPREAD_FLOOR))
     out['summary'] = summ
     os.makedirs('gpurun_out', exist_ok=True)
     path = 'gpurun_out/parity_%s.json' % tag
-    json.dump(out, open(path, 'w'), indent=1)
+
+    def compact(x):
+        if isinstance(x, float):
+            return float('%.4g' % x) if x == x and abs(x) != float('inf') else (None if x != x else (1e300 if x > 0 else -1e300))
+        if isinstance(x, dict):
+            return {k: compact(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [compact(v) for v in x]
+        return x
+    json.dump(compact(out), open(path, 'w'), separators=(',', ':'))
     print('wrote', path, json.dumps(out['summary']))
 
 

@@ -13,10 +13,13 @@ def short(name):
 path, sq_dir, stats = sys.argv[1:4]
 d = json.load(open(path))
 acc = collections.defaultdict(list)
+gui = collections.defaultdict(list)
 for f in glob.glob(os.path.join(sq_dir, '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == 'SQ_ACTIVE_INST_VALU' and 'gendr' in r['Kernel_Name']:
             acc[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
+        if r['Counter_Name'] == 'GRBM_GUI_ACTIVE' and 'gendr' in r['Kernel_Name']:
+            gui[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
 quad = {}
 for k, v in acc.items():
     g = max(x[0] for x in v)
@@ -42,8 +45,20 @@ if not dur:
 d['kernel_sha'] = build.source_sha()
 d['valu_active_quad_cycles'] = quad
 d['avg_kernel_us'] = dur
-d['valu_busy'] = {k: quad[k] * 4 / (1024 * dur[k] * 1e-6 * 2.4e9) for k in quad if k in dur and dur[k] > 0}
-d['valu_busy_note'] = ('SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * median kernel duration in the same counter run * 2.4 GHz nominal clock); '
-                       'the counter run uses the traced batch of profiles/run_all.sh (C4: 32, C5: 8 frames), not the bench batch')
+# GPU cycles of the launch from the SAME pass (GRBM_GUI_ACTIVE: no assumption about the clock the run happened at -- round 3
+# divided by duration * 2.4 GHz and printed occupations above 1 for runs at a lower clock); fallback: the nominal clock
+cycles = {}
+for k, v in gui.items():
+    g = max(x[0] for x in v)
+    vals = [x[1] for x in v if x[0] == g]
+    cycles[k] = sum(vals) / len(vals)
+d['gpu_cycles'] = cycles
+d['valu_busy'] = {k: (quad[k] * 4 / (1024 * cycles[k]) if cycles.get(k) else quad[k] * 4 / (1024 * dur[k] * 1e-6 * 2.4e9))
+                  for k in quad if (cycles.get(k) or (k in dur and dur[k] > 0))}
+d['valu_busy_note'] = ('SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * GRBM_GUI_ACTIVE of the same launch in the same counter pass) '
+                       '[without that counter: / (median kernel duration * 2.4 GHz nominal), +-10 %]; the counter pass runs tools/kbench.py at '
+                       'the batch recorded in sq_batch, the traffic passes run bench.py at the batch recorded in traffic_batch')
+if len(sys.argv) > 4:
+    d['sq_batch'] = int(sys.argv[4])
 json.dump(d, open(path, 'w'), indent=1)
 print(json.dumps({k: round(v, 3) for k, v in d['valu_busy'].items()}), d['kernel_sha'])

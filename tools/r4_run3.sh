@@ -1,6 +1,8 @@
 cd $GRAFT_REPO_ROOT
-bash profiles/run_pmc.sh r04_c4_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY" --config c4 --modes normal --batch 32 > /dev/null 2>&1
-bash profiles/run_pmc.sh r04_c4_b "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MUL_F64 SQ_LDS_BANK_CONFLICT" --config c4 --modes normal --batch 32 > /dev/null 2>&1
-for P in a b; do python tools/pmc_summary.py gpurun_out/pmc_r04_c4_$P render; done > gpurun_out/r04_c4_sq_now.txt
-cat gpurun_out/r04_c4_sq_now.txt
-rm -rf gpurun_out/pmc_r04_c4_a gpurun_out/pmc_r04_c4_b
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_round3.py -q -x 2>&1 | tail -3
+python tools/kbench.py --config c4 --batch 32 --modes normal --iters 5 | grep normal
+python tools/kbench.py --config c2 --modes normal --iters 30 | grep normal
+python tools/kbench.py --config c3 --modes normal --iters 30 | grep normal
+python tools/kbench.py --config c5 --batch 8 --modes normal --iters 8 | grep normal
+python tools/shapebench.py 64 24 dist_func=logistic aggr_rgb_func=hard dist_eps=100

@@ -23,5 +23,11 @@ for k in vals['FETCH_SIZE']:
     res['read_bytes_corrected'][k] = rd
     res['write_bytes'][k] = wr
     res['hbm_bytes_per_launch'][k] = rd + wr
+# the batch the traffic passes ran at: from the bench line of the pass itself
+try:
+    line = [l for l in open(os.path.join(out_dir, 'FETCH_SIZE.log')) if l.startswith('{')][-1]
+    res['traffic_batch'] = json.loads(line)['config']['global_batch']
+except Exception:
+    res['traffic_batch'] = None
 json.dump(res, open(os.path.join(out_dir, 'pmc_%s.json' % cfg), 'w'), indent=1)
 print(json.dumps(res, indent=1))
