@@ -53,11 +53,15 @@ for k, v in gui.items():
     vals = [x[1] for x in v if x[0] == g]
     cycles[k] = sum(vals) / len(vals)
 d['gpu_cycles'] = cycles
-d['valu_busy'] = {k: (quad[k] * 4 / (1024 * cycles[k]) if cycles.get(k) else quad[k] * 4 / (1024 * dur[k] * 1e-6 * 2.4e9))
-                  for k in quad if (cycles.get(k) or (k in dur and dur[k] > 0))}
-d['valu_busy_note'] = ('SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * GRBM_GUI_ACTIVE of the same launch in the same counter pass) '
-                       '[without that counter: / (median kernel duration * 2.4 GHz nominal), +-10 %]; the counter pass runs tools/kbench.py at '
-                       'the batch recorded in sq_batch, the traffic passes run bench.py at the batch recorded in traffic_batch')
+d['valu_busy'] = {k: quad[k] * 4 / (1024 * dur[k] * 1e-6 * 2.4e9) for k in quad if k in dur and dur[k] > 0}
+# GRBM_GUI_ACTIVE is summed over the 8 XCDs and covers the whole dispatch (start-up, drain, overlap with its neighbours): for
+# the long render kernels it gives a clock-independent second opinion, for the short geometry kernels it over-counts
+d['valu_busy_by_gpu_cycles'] = {k: quad[k] * 4 / (1024 * cycles[k] / 8.0) for k in quad if cycles.get(k)}
+d['valu_busy_note'] = ('valu_busy = SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * median kernel duration IN THE SAME counter pass * 2.4 GHz '
+                       'nominal clock): +-10 % (the clock of the pass is not recorded; values a few percent above 1 mean "fully occupied"); '
+                       'valu_busy_by_gpu_cycles = the same over GRBM_GUI_ACTIVE / 8 XCDs of the same launch (no clock assumption, but the '
+                       'counter spans the whole dispatch); the counter pass runs tools/kbench.py at the batch recorded in sq_batch, the traffic '
+                       'passes run bench.py at the batch recorded in traffic_batch')
 if len(sys.argv) > 4:
     d['sq_batch'] = int(sys.argv[4])
 json.dump(d, open(path, 'w'), indent=1)
