@@ -745,7 +745,7 @@ static int face_setup_impl(const float* faces, const float* textures, void* work
         // region tags (CoverEnt) pay where entries cover most of a tile -- a cull radius of a tile's width and more -- and only the
         // kernels with the dense path read them (measured at BASELINE config 2, where neither holds: +5 us in the coverage kernel)
         const KernelEntry& k = pick_kernel(p, texm, silhouette);
-        const bool dense = k.key.dist < 0 || k.key.dist == kLogistic;           // dense_path<DIST>() of gendr_kernels.h
+        const bool dense = k.key.dist < 0 || k.key.dist == kLogistic || (GENDR_DENSE_GAMMA && k.key.dist == kGamma);           // dense_path<DIST>() of gendr_kernels.h
         a.want_tags = (dense && cull_r * (float)p->image_size * 0.5f >= (float)kTile) ? 1 : 0;
     }
     const int cblocks = render_blocks(a.total_blocks) * GENDR_COVER_GRID_MUL;

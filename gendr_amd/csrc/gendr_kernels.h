@@ -1669,7 +1669,10 @@ constexpr int kFillCodes = kChunkBatches * 64, kCodeCap = kFillCodes + 64;
 // the registers.
 template <int DIST> __host__ __device__ constexpr bool dense_path()
 {
-    return DIST < 0 || DIST == kLogistic;      // the runtime-dispatch kernels, and BASELINE config 4's
+#ifndef GENDR_DENSE_GAMMA
+#define GENDR_DENSE_GAMMA 0
+#endif
+    return DIST < 0 || DIST == kLogistic || (GENDR_DENSE_GAMMA && DIST == kGamma);      // the runtime-dispatch kernels, and BASELINE config 4's
 }
 
 #ifndef GENDR_PIXEL_MODE_AVG

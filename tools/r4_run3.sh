@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_round3.py -q -x 2>&1 | tail -3
-python tools/kbench.py --config c4 --batch 32 --modes normal --iters 5 | grep normal
-python tools/kbench.py --config c2 --modes normal --iters 30 | grep normal
-python tools/kbench.py --config c3 --modes normal --iters 30 | grep normal
-python tools/kbench.py --config c5 --batch 8 --modes normal --iters 8 | grep normal
-python tools/shapebench.py 64 24 dist_func=logistic aggr_rgb_func=hard dist_eps=100
+cp gendr_amd/libgendr_hip.so /tmp/base.so
+for rep in 1 2; do for f in /tmp/base.so v_dg.so; do cp $f gendr_amd/libgendr_hip.so; echo "== $f"; python tools/kbench.py --config c5 --batch 16 --modes normal --iters 6 | grep normal; done; done
+cp v_dg.so gendr_amd/libgendr_hip.so
+timeout 600 python -m pytest tests/test_gpu_c5.py tests/test_gpu_fullsize.py -q -x 2>&1 | tail -2
+cp /tmp/base.so gendr_amd/libgendr_hip.so
