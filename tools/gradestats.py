@@ -48,3 +48,20 @@ for x in range(8):
     print('queue %d: %4d listed, %4d live, hint flag %d, split 8/4/2-fold: %d %d %d -> %d work items | pairs per tile max %d, p90 %d, p50 %d, entries p50 %d'
           % (x, n, live, control[x * 1024 + 1], g8, g4, g2, live + 7 * g8 + 3 * g4 + g2,
              int(pw.max()) if n else 0, int(np.percentile(pw, 90)) if n else 0, int(np.median(pw)) if n else 0, int(np.median(info[qb:qb + n, 2])) if n else 0))
+
+# region tags of the coverage entries (CoverEnt.npix bits 8..9) and how full the entries are
+ent_off = off + a256(tiles * 16)
+ents = w[ent_off:].view(np.int32)
+tags = np.zeros(4, np.int64); px = np.zeros(4, np.int64); full = 0; n_ent = 0
+for x in range(8):
+    n = int(control[x * 1024]); qb = x * tiles // 8
+    for tile, first, cnt, pairs in info[qb:qb + n]:
+        if first < 0 or cnt <= 0:
+            continue
+        e = ents[first * 4:(first + cnt) * 4].reshape(cnt, 4)
+        t = (e[:, 1] >> 8) & 3; p = e[:, 1] & 255
+        for k in range(4):
+            tags[k] += int((t == k).sum()); px[k] += int(p[t == k].sum())
+        full += int((p == 64).sum()); n_ent += cnt
+print('entries %d, with all 64 pixels %.1f %%, pixels per entry %.1f; region tag none / edge 0 / 1 / 2: %s of the entries, %s of the pairs'
+      % (n_ent, 100.0 * full / max(n_ent, 1), px.sum() / max(n_ent, 1), np.round(100.0 * tags / max(tags.sum(), 1), 1), np.round(100.0 * px / max(px.sum(), 1), 1)))
