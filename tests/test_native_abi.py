@@ -84,9 +84,13 @@ def test_workspace_bytes(native_lib):
     tiles = 2 * 32 * 32
     pool = 2 * (32 * tiles + 64 * 2 * 1280) * 16          # radius of 1.3 pixels: 64 per face; fewer than 8 batch items: doubled
     # + the pair hints (ABI 6; automatic: on for this 1.3-pixel cull radius): one 16-byte slot per pool entry
-    # + the faces with a loose cull box (loose_faces_kernel): a flag (4 B) and a pixel box (16 B) per face, a list of 16 ints per image
-    loose = 2 * 1280 * 4 + 2 * 1280 * 16 + 256
-    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + pool + tiles * 16 + loose + control
+    # (the per-image lists of faces with a loose cull box exist from 1024^2 only -- loose_faces_kernel; below that the coverage kernel
+    # resolves them without any buffer of its own: round 4)
+    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + pool + tiles * 16 + control
+    # 1024^2: a flag (4 B) and a pixel box (16 B) per face, a list of 16 ints per image
+    big1 = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(_params(image_size=1024)))
+    q1 = _params(image_size=1016)
+    assert big1 - native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(q1)) >= 2 * 1280 * 4 + 2 * 1280 * 16 + 256
     q = _params(image_size=256)
     q.pair_hints = -1
     assert native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(q)) == n - pool
@@ -96,7 +100,7 @@ def test_workspace_bytes(native_lib):
     assert big < 32 * 1280 * (64 + 224 + 20) + big_tiles * (20 * 8 + 4 + 16) + 2 * 16 * (32 * big_tiles + 20000 * 32 * 1280) + control + 12 * 256 + 32 * 64
     # tiny problems: the pool never exceeds one slot per (tile, face)
     small = native_lib.gendr_workspace_bytes(1, 2, 1, ctypes.byref(_params(image_size=8)))
-    assert small == 256 * 4 + 512 + 256 + 256 + 3 * 256 + control    # four sub-256-byte parts, 2 records (448 B), an 8-slot pool and its hint slots, the three loose-face parts, the counters
+    assert small == 256 * 4 + 512 + 256 + 256 + control    # four sub-256-byte parts, 2 records (448 B), an 8-slot pool and its hint slots, the counters
     assert native_lib.gendr_workspace_bytes(2, 1280, 3, ctypes.byref(_params(image_size=256, texture_type='vertex'))) > n
     assert native_lib.gendr_workspace_bytes(2, 1280, 0, ctypes.byref(p)) == 0
 

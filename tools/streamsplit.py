@@ -14,7 +14,7 @@ import parity
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default='c2'); ap.add_argument('--iters', type=int, default=30); ap.add_argument('--parts', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=None); ap.add_argument('--graph', action='store_true', help='time the replay of a captured HIP graph (no host launch gaps)')
     args = ap.parse_args()
     cfg = B.CONFIGS[args.config]
     Bn = args.batch or cfg['batch']; isz = cfg['image_size']
@@ -82,6 +82,19 @@ def main():
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
+        if args.graph:
+            cs = torch.cuda.Stream()
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                fn()
+            torch.cuda.current_stream().wait_stream(cs)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                keep = fn()
+            fn = g.replay
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(args.iters):
