@@ -1,0 +1,88 @@
+"""Round-4 paths of the render kernels: dense entries, pixel mode and region tags (long-tailed distributions: an entry covers
+most of its tile), on a scene small enough for the oracle -- exercised for certain (the workspace is read back: entries with
+all 64 pixels, tiles over the pixel-mode threshold and tagged entries must all occur) and held to the all-pairs traversal bit
+for bit, to the oracle by the element-wise rule, and to the reference's own kernels by the flat gate."""
+import numpy as np
+import pytest
+import torch
+
+import criteria
+import parity
+import pin
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(dist_func='logistic', dist_scale=3e-2, aggr_alpha_func='probabilistic', aggr_rgb_func='softmax', double_side=False)
+
+
+def _entries(ws, B, nf, isz, rec_floats):
+    """(queue records [tiles,4], entries [n,4]) of a float32 workspace (layout: gendr_capi.hip workspace_layout)."""
+    w = ws.cpu().numpy()
+    a256 = lambda v: (v + 255) // 256 * 256
+    tiles_x = (isz + 7) // 8
+    tiles = B * tiles_x * tiles_x
+    chunks = (nf + 63) // 64
+    off = a256(B * nf * 16 * 4) + a256(B * nf * rec_floats * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
+    info = w[off:off + tiles * 16].view(np.int32).reshape(tiles, 4)
+    ents = w[off + a256(tiles * 16):].view(np.int32)
+    return info, ents
+
+
+@pytest.mark.parametrize("rgb", ['softmax', 'hard'])
+def test_pixel_mode_dense_entries_and_region_tags(oracle_mod, native_lib, rgb):
+    from gendr_amd.functional import renderer as R
+    fv, tex = scenes.sphere(B=2)
+    isz = 64
+    opts = dict(OPTS, aggr_rgb_func=rgb)
+    grad = np.random.RandomState(2).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
+    # the paths are taken: read the coverage entries back
+    o, extra = parity.split_options(opts)
+    p = parity.hip_params(isz, o, extra)
+    faces = torch.from_numpy(fv).reshape(2, -1, 9).cuda().contiguous()
+    t = torch.from_numpy(tex).cuda().contiguous()
+    _, _, ws = R.native_forward(faces, t, p)
+    torch.cuda.synchronize()
+    info, ents = _entries(ws, 2, fv.shape[1], isz, 56)
+    listed = info[(info[:, 1] >= 0) & (info[:, 2] > 0)]
+    assert len(listed) > 0
+    pixel_mode = listed[listed[:, 3] >= 36 * listed[:, 2]]
+    assert len(pixel_mode) > len(listed) // 4, 'the scene should put a good share of its tiles over the pixel-mode threshold'
+    full = tagged = total = 0
+    for tile, first, cnt, pairs in listed:
+        e = ents[first * 4:(first + cnt) * 4].reshape(cnt, 4)
+        full += int(((e[:, 1] & 255) == 64).sum())
+        tagged += int((((e[:, 1] >> 8) & 3) != 0).sum())
+        total += cnt
+    assert full > 0 and tagged > total // 10, (full, tagged, total)
+    # ... and change nothing: culled (entries, pixel mode, tags) == all pairs (no pool: the reference's own traversal)
+    a = parity.run_hip(fv, tex, isz, opts, grad)
+    b = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
+    assert np.array_equal(a['rgba'], b['rgba'], equal_nan=True) and np.array_equal(a['aggrs_info'], b['aggrs_info'], equal_nan=True)
+    for k in ('grad_faces', 'grad_textures'):
+        assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * max(1e-30, float(np.abs(b[k]).max())), k
+    bad, _, _ = criteria.check_case(fv, tex, isz, opts, a, grad)
+    assert not bad, bad
+    if parity.reference_available():
+        r = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
+        c = parity.run_oracle(fv, tex, isz, opts, grad, np.float32)
+        assert np.array_equal(a['rgba'], r['rgba']), 'logistic / probabilistic: rgba bit-identical to the reference\'s kernels'
+        m = pin.measure(a, r, c['abs_faces'], c['abs_textures'])
+        assert all(x['max'] <= 1e-5 for x in m.values()), m
+
+
+def test_silhouette_kernels_take_the_same_paths(native_lib):
+    """The alpha-only kernels share for_each_batch: alpha == render()[:, 3] bit for bit in the dense regime as well."""
+    from gendr_amd.functional.silhouette import render_silhouette
+    from gendr_amd.functional.renderer import render
+    fv, tex = scenes.sphere(B=2)
+    f = torch.from_numpy(fv).cuda().requires_grad_(True)
+    t = torch.from_numpy(tex).cuda()
+    kw = dict(image_size=64, dist_func='logistic', dist_scale=3e-2, aggr_alpha_func='probabilistic')
+    full = render(f, t, aggr_rgb_func='hard', double_side=False, **kw)
+    alpha = render_silhouette(f, **kw)
+    assert torch.equal(alpha, full[:, 3])
+    g = torch.randn_like(alpha)
+    ga, = torch.autograd.grad(alpha, f, g, retain_graph=True)
+    gb, = torch.autograd.grad(full[:, 3], f, g)
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
