@@ -2422,9 +2422,13 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     const unsigned long long my_rows = sub_tile_mask(split_log2, sub);
     const bool pixel_mode = dense_path<DIST>() && tile_in_pixel_mode(ti, split_log2);
     const PairHints* hint_slot = (hinted_q && split_log2 == 0 && ti.y >= 0 && !pixel_mode) ? a.hints + ti.y : nullptr;   // next batch's hints
-    if (hint_slot && ti.w <= 4 * 64) {
+    if (hint_slot && !dense_path<DIST>() && ti.w <= 4 * 64) {
         // a tile whose few batches hold no pair with a gradient is done before its pixel inputs are fetched (an image with a
-        // face seen edge-on lists that face -- no error bound, 64 dead pairs -- in every one of its tiles)
+        // face seen edge-on lists that face -- no error bound, 64 dead pairs -- in every one of its tiles).  Not in the kernels
+        // with the dense path: a dense entry of the tile runs outside the batches, so the batches' hints say nothing about its
+        // pairs and the tile's pair count says nothing about the number of batches (found by tools/fuzz_parity.py in round 4: a
+        // tile whose only live pairs belonged to a dense entry was skipped -- the texture gradient of an image-filling face came
+        // out 40 % short)
         unsigned long long all_dead = ~0ull;
         for (int k = 0; k < ((ti.w + 63) >> 6); k++) {
             const GENDR_CONST_AS unsigned long long* hp = (const GENDR_CONST_AS unsigned long long*)(hint_slot + k);
