@@ -62,9 +62,6 @@
 #define GENDR_BWD_WAVES 4
 #endif
 
-#ifndef GENDR_SPLIT_MIN
-#define GENDR_SPLIT_MIN 8
-#endif
 
 #ifndef GENDR_TRACE
 #define GENDR_TRACE 0          // 1: every wave of the backward kernel leaves time stamps (diagnostic build, tools/wave_trace.py)
@@ -217,7 +214,6 @@ __host__ __device__ constexpr int record_floats(int texm) { return texm == kTexS
 
 constexpr int kTile    = 8;     // one wavefront renders an 8x8 pixel tile
 constexpr int kThreads = 64;    // one wave-tile per workgroup (measured: 64 > 128 > 256 > 512 threads, +6 % over 256)
-constexpr int kSplitMin = GENDR_SPLIT_MIN;   // a face's pairs are split over two batches if at least this many fit into the open one
 
 // Control block (ints) at the end of the workspace, zeroed by face_setup_kernel on every call:
 //   [x * kCtlStride], x = 0..7     : length of tile queue x,
