@@ -26,7 +26,11 @@ def _entries(ws, B, nf, isz, rec_floats):
     off = a256(B * nf * 16 * 4) + a256(B * nf * rec_floats * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
     info = w[off:off + tiles * 16].view(np.int32).reshape(tiles, 4)
     ents = w[off + a256(tiles * 16):].view(np.int32)
-    return info, ents
+    # only the first `queue length` records of each of the 8 queues were written by this call (the rest of the region is whatever
+    # the allocator handed out); the lengths sit in the control block at the end of the workspace
+    control = w[len(w) - 24 * 1024 * 4:].view(np.int32)
+    rows = [info[x * tiles // 8:x * tiles // 8 + int(control[x * 1024])] for x in range(8)]
+    return np.concatenate(rows), ents
 
 
 @pytest.mark.parametrize("rgb", ['softmax', 'hard'])
