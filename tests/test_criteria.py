@@ -92,3 +92,22 @@ def test_pin_table_is_present_and_small():
     n_cases = len(pin.MATRIX) * len(pin.SCENES) + len(pin.FULL)
     assert len(t['default']) <= n_cases // 10, sorted(t['default'])
     assert not any(k in t['default'] for k in ('C2', 'C4')), 'BASELINE configs 2 and 4 meet a flat 1e-5'
+
+
+def test_flat_gate_logic():
+    """tests/pin.py on synthetic numbers: an untabled case is held to 1e-5 flat; a tabled (case, tensor) to twice its tabulated
+    maximum, 99th percentile and share above 1e-5 -- so a systematic error fails a tabled case too."""
+    import pin
+    table = dict(default={'X': {'grad_faces': dict(max=1e-3, p99=3e-5, frac=0.02)}})
+    ok = dict(rgba=dict(max=0.0, p99=0.0, frac=0.0, n=100), grad_faces=dict(max=9e-6, p99=1e-6, frac=0.0, n=100))
+    assert not pin.flat_failures('Y', ok, table)
+    assert pin.flat_failures('Y', dict(ok, grad_faces=dict(max=2e-5, p99=1e-6, frac=0.01, n=100)), table)
+    inside = dict(ok, grad_faces=dict(max=1.5e-3, p99=5e-5, frac=0.03, n=100))
+    assert not pin.flat_failures('X', inside, table)
+    assert pin.flat_failures('X', dict(ok, grad_faces=dict(max=1.5e-3, p99=1e-4, frac=0.9, n=100)), table)      # a 1e-4 error everywhere
+    assert pin.flat_failures('X', dict(ok, rgba=dict(max=2e-5, p99=0.0, frac=0.01, n=100)), table)              # another tensor of the case: flat
+    # the spread gate of the fast variant: quantile by quantile against the reference's own two builds
+    spread = dict(rgba=dict(p50=0.0, p90=1e-6, p99=1e-4, p999=2e-3, frac=0.04, max=5.0, n=1000))
+    m_in = dict(rgba=dict(p50=0.0, p90=5e-5, p99=3e-4, p999=5e-3, frac=0.05, max=9e5, n=1000))
+    assert not pin.spread_failures('X', m_in, spread)
+    assert pin.spread_failures('X', dict(rgba=dict(m_in['rgba'], p99=1e-3)), spread)
