@@ -713,7 +713,7 @@ def main():
                             scaled = '; traffic measured at batch %d and scaled to this line\'s %d frames on rank 0' % (tb, B)
                         source = ('profiles/pmc_%s.json (kernel sources %s): rocprofv3 --pmc passes (profiles/run_all.sh): traffic = '
                                   '2*FETCH_SIZE+WRITE_SIZE of bench.py at batch %s%s; valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * '
-                                  'GRBM_GUI_ACTIVE of the same launch), tools/kbench.py at batch %s; not re-measured in this run'
+                                  'kernel duration of the same counter pass * 2.4 GHz nominal), tools/kbench.py at batch %s; not re-measured in this run'
                                   % (args.config, pmc['kernel_sha'], tb, scaled, pmc.get('sq_batch')))
                     else:
                         source = ('profiles/pmc_%s.json was collected on other kernel sources (%s, now %s): traffic and valu_busy withheld'
