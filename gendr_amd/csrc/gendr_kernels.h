@@ -13,7 +13,7 @@
 //     box outside of which the reference itself would skip the pair (kernel.cu:747,769,784); the binning kernel
 //     tests those boxes against every tile rectangle, leaves one bit per (tile, face) in HBM -- ascending face order
 //     for free, shared by forward and backward -- and queues the tiles that list anything (8 queues, one per XCD);
-//   * the coverage kernel (one wave per listed tile, eight faces per step, lane = (face, pixel row)) applies the exact
+//   * the coverage kernel (one wave per listed tile, sixteen faces per step, lane = (face, two pixel rows)) applies the exact
 //     per-pixel tests once and leaves, per tile, the list of (face, 64-bit pixel mask) entries that own at least one
 //     pixel -- shared by forward and backward, so neither render kernel looks at a face record before it has to;
 //   * the render kernels walk the tile queues.  Per tile they read the entry list (one coalesced load per 64 entries),
@@ -984,7 +984,7 @@ __device__ __forceinline__ void sample_colour(float* c, int& own, const float* w
 // Measured on the headline scene: a face touches only ~14 of a tile's 64 pixels, so evaluating "one face per
 // loop iteration, lane = pixel" leaves ~78 % of the lanes idle in the expensive stages.  Instead:
 //   coverage (cheap, once per forward call, cover_kernel): box test, barycentrics, edge reject for every pixel of the
-//            tile against every listed face, lane = (face, pixel row), eight faces per step -> per tile the entries
+//            tile against every listed face, lane = (face, two pixel rows), sixteen faces per step -> per tile the entries
 //            (face, pixel mask) in ascending face order;
 //   walk     the render kernels append the (pixel, face) pairs of the entries -- in ascending (face, pixel) order --
 //            to a wavefront-private list in LDS, together with the face's mask;
@@ -1359,12 +1359,12 @@ __global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GEN
 // coverage: which pixels of the tile does each listed face reach?  (once per forward call, shared by both passes)
 // ---------------------------------------------------------------------------------------------
 // One wavefront per listed tile (the same queue walk as the render kernels).  The tile's mask row is first unpacked
-// into an ascending face list in LDS.  Then eight faces are examined per step: lane = (face slot, pixel row), the lane
-// gathers its face's first record stage with vector loads -- eight records in flight per step instead of one
-// scalar-load round trip per face -- and walks the eight pixels of its row through the exact box / edge tests (same
-// functions, same operands as a per-pixel evaluation).  The eight row bytes of a face are OR-ed together across its
-// lanes; faces that own at least one pixel are appended, in ascending order, to the tile's slice of the entry pool
-// (eight 16-byte stores per step, contiguous).
+// into an ascending face list in LDS.  Then sixteen faces are examined per step: the four lanes of a quad share a face
+// slot, lane q of the quad takes pixel rows q and q + 4; the lane gathers its face's first record stage with vector loads
+// -- sixteen records in flight per step instead of one scalar-load round trip per face -- and finds, per row, the
+// interval of columns that passes the box / edge tests (see the step loop).  The eight row bytes of a face are OR-ed
+// together across its quad (two DPP steps); faces that own at least one pixel are appended, in ascending order, to the
+// tile's slice of the entry pool (up to sixteen 16-byte stores per step, contiguous).
 constexpr int kListCap = 128;      // faces unpacked per round (>= 64: one mask word must fit)
 
 __device__ __forceinline__ unsigned quad_or(unsigned v)
@@ -1383,7 +1383,8 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
     walk_init(tw, a, 1);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int slot = lane >> 3, prow = lane & 7;
+    // sixteen faces per step: the four lanes of a quad share a face, lane q of the quad tests pixel rows q and q + 4 of the tile
+    const int slot = lane >> 2, prow = lane & 3;
     for (; tw.next < tw.total; tw.next += tw.stride) {
         // The queue was appended to as the binning workgroups finished: the super-tiles under the object, with the most
         // faces to examine here, came last.  The waves take the slots from the back so that those start first.
@@ -1396,8 +1397,8 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
         const float* recs_g = a.records + (long)t.b * a.nf * REC;
         const unsigned long long* mrow = a.masks + (long)tile * a.chunks;
         const int row_a = t.y0 + prow;
-        const bool row_ok = row_a < a.is;
-        const float yp_a = pixel_coord(a.is - 1 - row_a, a.is, a.r_is);
+        const bool row_ok[2] = {row_a < a.is, row_a + 4 < a.is};
+        const float yp_r[2] = {pixel_coord(a.is - 1 - row_a, a.is, a.r_is), pixel_coord(a.is - 5 - row_a, a.is, a.r_is)};
         CoverEnt* out = a.entries + off;
         int nout = 0;
         float xs[8];                               // pixel centres of the tile's columns, and the nominal pixel pitch
@@ -1431,14 +1432,16 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 nlist += cnt;
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- eight faces per step
-            for (int i0 = 0; i0 < nlist; i0 += 8) {
+            // ---- sixteen faces per step (round 4: eight, one row per lane -- a wave of this kernel waits for the dependent loads of
+            // each step, face list -> record, far longer than it computes: half the steps, and the per-edge terms that do not
+            // depend on the row are shared by the lane's two rows)
+            for (int i0 = 0; i0 < nlist; i0 += 16) {
                 const bool has = i0 + slot < nlist;
                 const int fn = s_flist[has ? i0 + slot : i0];
                 float r[kRecStage1];
                 gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
-                unsigned m8 = 0u;
-                unsigned unproven = 0u;                     // region tag: what this lane's row leaves unproven (rows without a pixel: nothing)
+                unsigned m8[2] = {0u, 0u};
+                unsigned unproven = 0u;                     // region tag: what this lane's rows leave unproven (rows without a pixel: nothing)
                 // The entries only have to be a SUPERSET of the contributing pairs (every pair still meets the reference's own
                 // skip tests in the render kernels).  Along a pixel row each barycentric is linear in the column c = 0..7,
                 // w_k(c) = w_k(0) + c d_k, so the columns that pass all three edge thresholds and the cull box form ONE interval:
@@ -1452,9 +1455,12 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 // test (< 2^-13 columns up to 4096^2) are covered by widening the interval by kColSlack = 2^-8 column at either
                 // end.  A coefficient that is zero, tiny, infinite or NaN makes its constraint constant along the row (kept unless
                 // it provably fails); NaN never drops a pixel (v_max / v_min return the other operand).
-                if (has && row_ok && !(yp_a > r[kRecBox + 3] || yp_a < r[kRecBox + 2])) {
-                    constexpr float kSlack = 1.9073486328125e-06f;                     // 2^-19
-                    constexpr float kColSlack = 0.00390625f;                           // 2^-8
+                constexpr float kSlack = 1.9073486328125e-06f;                     // 2^-19
+                constexpr float kColSlack = 0.00390625f;                           // 2^-8
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const float yp_a = yp_r[rr];
+                    if (!(has && row_ok[rr] && !(yp_a > r[kRecBox + 3] || yp_a < r[kRecBox + 2]))) continue;
                     float lo = -1.f, hi = 9.f;                                         // the interval of columns, in column units
                     bool none = false;
 #pragma unroll
@@ -1475,13 +1481,13 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                     hi = fminf(hi, (r[kRecBox + 1] - xs[0]) * half_is);
                     const int c_first = max(0, (int)ceilf(fminf(lo, 16.f) - kColSlack));
                     const int c_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(hi, -2.f) + kColSlack));
-                    if (!none && c_last >= c_first) m8 = ((2u << c_last) - 1u) & ~((1u << c_first) - 1u);
+                    if (!none && c_last >= c_first) m8[rr] = ((2u << c_last) - 1u) & ~((1u << c_first) - 1u);
                     // Region tag (see CoverEnt): along the row's pixels c_first .. c_last every barycentric is linear, so its sign
                     // is settled by the two ends -- where both lie beyond a margin of 2^-19 (|a| + |b| + |c|) on the same side (the
                     // model w_k(0) + c d_k and the value barycentrics() computes for the pixel differ by less than half of that,
                     // see kSlack above).  Bits 0..2: w_k <= 0 NOT proven for the row; bits 3..5: w_k > 0 NOT proven.  NaN proves
                     // nothing.
-                    if (m8 && a.want_tags) {
+                    if (m8[rr] && a.want_tags) {
                         const float cf = (float)c_first, cl = (float)c_last;
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
@@ -1494,10 +1500,10 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                         }
                     }
                 }
-                const bool loose_l = has && __float_as_int(r[kRecLoose]) != 0;         // (the eight lanes of a slot hold the same record)
-                if (loose_l) m8 = 0u;
-                unsigned v = quad_or(m8 << (8 * (prow & 3)));            // lanes 8s..8s+3: rows 0-3, lanes 8s+4..8s+7: rows 4-7
-                unsigned hi = (unsigned)__shfl_down((int)v, 4);                        // lane 8s reads lane 8s+4 (rows 4-7)
+                const bool loose_l = has && __float_as_int(r[kRecLoose]) != 0;         // (the four lanes of a quad hold the same record)
+                if (loose_l) m8[0] = m8[1] = 0u;
+                unsigned v = quad_or(m8[0] << (8 * prow));                            // rows 0-3 of the face, in all four lanes of its quad
+                unsigned hi = quad_or(m8[1] << (8 * prow));                           // rows 4-7
                 // A face with a LOOSE cull box (face_setup_kernel: seen edge-on, no usable error bound -- its box is the reference's
                 // own margin and the binning kernel listed it in every tile of its image) is EVALUATED instead of bounded: lane =
                 // pixel of the tile, the record in scalar registers, barycentrics() and point_to_face() -- the render kernels'
@@ -1526,12 +1532,11 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                     const unsigned long long lm = __ballot(live);
                     if (lane == l) { v = (unsigned)lm; hi = (unsigned)(lm >> 32); my_pairs += __popcll(lm); }
                 }
-                my_pairs += __popc(m8);
-                // the rows' verdicts OR-ed over the face's eight lanes (as the row masks above), then the decision tree of
+                my_pairs += __popc(m8[0]) + __popc(m8[1]);
+                // the rows' verdicts OR-ed over the face's four lanes (as the row masks above), then the decision tree of
                 // kernel.cu:120-142 on the proven signs; a corner region whose obtuse-angle test (:122, :128, :134) would have to be
                 // evaluated per pixel gets no tag
-                unsigned up = quad_or(unproven);
-                up |= (unsigned)__shfl_down((int)up, 4);
+                const unsigned up = quad_or(unproven);
                 int tag = 0;
                 if (!loose_l && a.want_tags) {
                     const int bits = __float_as_int(r[kRecBits]);
