@@ -1442,10 +1442,11 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 gather_record<0, kRecStage1 / 4>(r, recs_g + (long)fn * REC);
                 unsigned m8[2] = {0u, 0u};
                 unsigned unproven = 0u;                     // region tag: what this lane's rows leave unproven (rows without a pixel: nothing)
-                // The entries only have to be a SUPERSET of the contributing pairs (every pair still meets the reference's own
-                // skip tests in the render kernels).  Along a pixel row each barycentric is linear in the column c = 0..7,
+                // Inside the record's box the entries only have to be a SUPERSET of the contributing pairs (every listed pair still
+                // meets the reference's distance and probability tests, :769 / :784, in the render kernels; the box itself is exact,
+                // see below).  Along a pixel row each barycentric is linear in the column c = 0..7,
                 // w_k(c) = w_k(0) + c d_k, so the columns that pass all three edge thresholds and the cull box form ONE interval:
-                // its ends are three quotients (t_k - w_k(0)) / d_k and two box quotients -- about half the vector instructions
+                // its ends are three quotients (t_k - w_k(0)) / d_k and the two box columns -- about half the vector instructions
                 // of testing the eight pixels one by one (round 2 stepped w_k from pixel to pixel: 30.0 -> 27.2 us at C2; the
                 // interval form: see DESIGN.md).  Error budget, all towards MORE pixels: the thresholds t_k are lowered by
                 // 2^-19 (|a| + |b| + |c|) -- the model w_k(0) + c d_k and the expression the thresholds were derived for
@@ -1457,6 +1458,17 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 // it provably fails); NaN never drops a pixel (v_max / v_min return the other operand).
                 constexpr float kSlack = 1.9073486328125e-06f;                     // 2^-19
                 constexpr float kColSlack = 0.00390625f;                           // 2^-8
+                // The record's BOX, though, is tested EXACTLY: it contains the reference's own border test (kernel.cu:747), which no
+                // later stage repeats for a listed pair -- with a small dist_eps it is the box, not the distribution's tail, that ends a
+                // face's reach (round 3's interval form widened the box ends by the column slack like the others and listed pixels whose
+                // centre lies up to 2^-8 column outside: found by tools/fuzz_parity.py case 255, a box edge 0.0015 column from a pixel
+                // centre).  Rows: the y test below is the per-pixel expression.  Columns (the same for both rows): the widened ends,
+                // then one exact step at either end on the pixel centre pixel_coord() returns -- the render kernels' x.
+                const float half_is = 0.5f * (float)a.is;                          // 1 / pitch
+                int cb_first = max(0, (int)ceilf(fminf(fmaxf((r[kRecBox + 0] - xs[0]) * half_is, -1.f), 16.f) - kColSlack));
+                int cb_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(fminf((r[kRecBox + 1] - xs[0]) * half_is, 9.f), -2.f) + kColSlack));
+                if (pixel_coord(t.x0 + cb_first, a.is, a.r_is) < r[kRecBox + 0]) cb_first++;       // (NaN ends exclude nothing, as in inside_box())
+                if (pixel_coord(t.x0 + cb_last, a.is, a.r_is) > r[kRecBox + 1]) cb_last--;
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
                     const float yp_a = yp_r[rr];
@@ -1476,11 +1488,8 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                         hi = fminf(hi, down ? q : 9.f);
                         none = none || (!up && !down && u > 8e-30f);                   // constant along the row (to 7e-30), and failing
                     }
-                    const float half_is = 0.5f * (float)a.is;                          // 1 / pitch
-                    lo = fmaxf(lo, (r[kRecBox + 0] - xs[0]) * half_is);
-                    hi = fminf(hi, (r[kRecBox + 1] - xs[0]) * half_is);
-                    const int c_first = max(0, (int)ceilf(fminf(lo, 16.f) - kColSlack));
-                    const int c_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(hi, -2.f) + kColSlack));
+                    const int c_first = max(cb_first, (int)ceilf(fminf(lo, 16.f) - kColSlack));
+                    const int c_last = min(cb_last, (int)floorf(fmaxf(hi, -2.f) + kColSlack));
                     if (!none && c_last >= c_first) m8[rr] = ((2u << c_last) - 1u) & ~((1u << c_first) - 1u);
                     // Region tag (see CoverEnt): along the row's pixels c_first .. c_last every barycentric is linear, so its sign
                     // is settled by the two ends -- where both lie beyond a margin of 2^-19 (|a| + |b| + |c|) on the same side (the

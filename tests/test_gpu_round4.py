@@ -109,3 +109,67 @@ def test_pair_hints_and_dense_entries_in_one_tile(oracle_mod, native_lib, opts):
         assert e.max() <= 2e-5, (k, float(e.max()), np.unravel_index(int(e.argmax()), e.shape))
     e = parity.rel_error(with_hints['grad_textures'], o['grad_textures'], scale=o['abs_textures'], floor=parity.GRAD_FLOOR)
     assert e.max() <= 1e-3, float(e.max())          # (against the oracle: the bug was 0.4)
+
+
+@pytest.mark.parametrize("isz", [8, 64, 100])
+def test_box_edge_next_to_a_pixel_centre(oracle_mod, native_lib, isz):
+    """The reference's border test (kernel.cu:747: x > max + sqrt(eps * scale) || x < min - ... ) is what ends a face's reach when
+    dist_eps is small -- no later stage repeats it for a listed pair, so the coverage kernel's box test has to be the per-pixel
+    expression, not a widened estimate.  (Round 3's column intervals widened the box ends by 2^-8 column with the edge thresholds:
+    tools/fuzz_parity.py case 255 had a box edge 0.0015 column outside a pixel centre and rendered that column; 16 of 2304 rgba elements
+    off by up to 0.7.)  Faces whose box edges -- left, right, bottom, top -- lie a few ulps to 3e-3 column on either side of a pixel
+    centre: culled == all-pairs bit for bit (the all-pairs traversal applies the reference's tests pixel by pixel; it is what the
+    pin tests hold against the reference's kernels)."""
+    opts = dict(dist_eps=1.5, dist_scale=0.2)
+    sthr = float(np.sqrt(np.float32(np.float32(1.5) * np.float32(0.2))))
+    pitch = 2.0 / isz
+    centre = lambda i: (2 * i + 1 - isz) / isz
+    faces = []
+    rs = np.random.RandomState(5)
+    for side in range(4):
+        for delta in (-3e-3, -1e-3, -1e-4, -2e-7, 0.0, 2e-7, 1e-4, 1e-3, 3e-3):
+            i = int(rs.randint(1, isz - 1))
+            edge = centre(i) + delta * pitch                      # where the box edge is to lie
+            j = centre(int(rs.randint(isz // 4, 3 * isz // 4)))  # the face's position along the other axis
+            ext = 0.05
+            # ZERO-AREA faces (two corners coincide): their error bound is infinite, so their cull box is the reference's border and
+            # nothing else -- and their computed distances are whatever the clamped determinant (kernel.cu:653) makes of them, so a
+            # pixel just outside the border is not caught by the distance test :769 either (a well-conditioned face hides the
+            # defect: beyond its border the squared distance exceeds dist_eps * dist_scale by construction)
+            if side == 0:   lo_x, lo_y = edge + sthr, j                  # left border  = min x - sthr
+            elif side == 1: lo_x, lo_y = edge - sthr - ext, j            # right border = max x + sthr
+            elif side == 2: lo_x, lo_y = j, edge + sthr                  # bottom
+            else:           lo_x, lo_y = j, edge - sthr - ext            # top
+            for kind in range(2):
+                if kind == 0: tri = [[lo_x, lo_y + ext, 2.0], [lo_x, lo_y + ext, 2.0], [lo_x + ext, lo_y, 4.3]]
+                else:         tri = [[lo_x, lo_y, 2.0], [lo_x + ext, lo_y + ext, 3.0], [lo_x + 0.5 * ext, lo_y + 0.5 * ext, 2.5]]    # three corners on a line
+                faces.append(tri)
+    fv = np.asarray(faces, np.float32)[None]                                                                  # [1, nf, 3, 3]
+    fv = np.concatenate([fv, fv[:, ::-1] * np.float32([1, -1, 1])], 0)                                        # a second image, mirrored
+    nf = fv.shape[1]
+    tex = np.random.RandomState(6).rand(2, nf, 4, 3).astype(np.float32)
+    grad = np.random.RandomState(7).randn(2, 4, isz, isz).astype(np.float32)
+    for one in (None, 0, 17, 40, nf - 1):                          # all faces together, and single faces (nothing else to hide behind)
+        f1, t1 = (fv, tex) if one is None else (fv[:, one:one + 1], tex[:, one:one + 1])
+        a = parity.run_hip(f1, t1, isz, opts, grad)
+        b = parity.run_hip(f1, t1, isz, dict(opts, cull=0), grad)
+        assert np.array_equal(a['rgba'], b['rgba'], equal_nan=True) and np.array_equal(a['aggrs_info'], b['aggrs_info'], equal_nan=True), one
+        for k in ('grad_faces', 'grad_textures'):
+            assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * max(1e-30, float(np.abs(b[k]).max())), (one, k)
+    if isz == 8:
+        # the face of the fuzz case itself (image 7, face 1 of tools/fuzz_parity.py 500 0, case 255): border at x = -0.37462, the
+        # centres of pixel column 2 at -0.375; before the fix the culled traversal rendered rows 2-5 of that column (rgba off by 0.5)
+        f1 = np.float32([[[[0.17310063540935516, -0.044718850404024124, 2.000278949737549],
+                           [0.17310063540935516, -0.044718850404024124, 2.000278949737549],
+                           [0.2192317247390747, -0.0495893619954586, 4.278071880340576]]]])
+        for shift in (0.0, 0.25, -0.5):                       # ... and the same face in front of other columns
+            f2 = f1 + np.float32([shift, 0, 0])
+            t2 = np.random.RandomState(8).rand(1, 1, 4, 3).astype(np.float32)
+            a = parity.run_hip(f2, t2, isz, opts, None)
+            b = parity.run_hip(f2, t2, isz, dict(opts, cull=0), None)
+            assert np.array_equal(a['rgba'], b['rgba'], equal_nan=True) and np.array_equal(a['aggrs_info'], b['aggrs_info'], equal_nan=True), shift
+    # every face alone, forward only
+    for k in range(nf):
+        a = parity.run_hip(fv[:, k:k + 1], tex[:, k:k + 1], isz, opts, None)
+        b = parity.run_hip(fv[:, k:k + 1], tex[:, k:k + 1], isz, dict(opts, cull=0), None)
+        assert np.array_equal(a['rgba'], b['rgba'], equal_nan=True), k

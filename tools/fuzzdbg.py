@@ -29,3 +29,16 @@ for case in range(n_cases):
         for k in ('grad_faces', 'grad_textures'):
             d = np.abs(h[k].reshape(o[k].shape) - o[k]); i = np.unravel_index(int(d.argmax()), d.shape)
             print('   %-10s %-14s max |diff| %.3g at %s: hip %.6g oracle %.6g' % (label, k, d.max(), i, h[k].reshape(o[k].shape)[i], o[k][i]))
+    # the forward result against everything that can arbitrate: the restatement in float and double, the reference's own kernels in
+    # both builds (oracle/_ref, when present) -- an O(1) difference on a few pixels that the reference's two builds also show between
+    # each other is the closest-point formula's ill-conditioning, not a defect of either
+    h = parity.run_hip(fv, tex, isz, opts, grad)
+    others = [('oracle f32', parity.run_oracle(fv, tex, isz, opts, grad, np.float32)), ('oracle f64', parity.run_oracle(fv, tex, isz, opts, grad, np.float64))]
+    if parity.reference_available():
+        others += [('ref kernels', parity.run_reference(fv, tex, isz, opts, grad, np.float32)), ('ref fma build', parity.run_reference(fv, tex, isz, opts, grad, np.float32, variant='render_fma'))]
+    for label, r in others:
+        d = np.abs(h['rgba'].astype(np.float64) - r['rgba'].reshape(h['rgba'].shape)); i = np.unravel_index(int(d.argmax()), d.shape)
+        print('   rgba hip vs %-14s max |diff| %.3g at %s (hip %.6g, other %.6g); elements > 1e-5: %d' % (label, d.max(), i, h['rgba'][i], r['rgba'].reshape(h['rgba'].shape)[i], int((d > 1e-5).sum())))
+    for (la, ra), (lb, rb) in ((others[0], others[1]),) + (((others[2], others[3]), (others[2], others[0])) if len(others) > 2 else ()):
+        d = np.abs(ra['rgba'].astype(np.float64) - rb['rgba'].astype(np.float64).reshape(ra['rgba'].shape))
+        print('   rgba %-14s vs %-14s max |diff| %.3g; elements > 1e-5: %d' % (la, lb, d.max(), int((d > 1e-5).sum())))
