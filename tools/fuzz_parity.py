@@ -1,5 +1,5 @@
 """Randomised HIP-vs-oracle check over shapes the fixed suites do not enumerate (run on the GPU box):
-    python tools/fuzz_parity.py [n_cases] [seed]
+    python tools/fuzz_parity.py [n_cases] [seed] [smalleps]
 Random batch size, face count (around the 64-face chunk boundaries), image size (odd sizes, sizes with empty 64x64
 super-tiles), texture layout and option set; the acceptance rule of tests/criteria.py; also culled == all-pairs."""
 import os, sys
@@ -10,6 +10,8 @@ import criteria, parity, scenes
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+small_eps = len(sys.argv) > 3 and sys.argv[3] == 'smalleps'
+small_rs = np.random.RandomState(77)           # (its own stream: the draw of everything else stays the plain campaign's)
 names = [n for n, _ in scenes.OPTION_MATRIX]
 bad = 0
 for case in range(n_cases):
@@ -29,6 +31,10 @@ for case in range(n_cases):
     opts['T'] = T
     # longer tails now and then: entries that cover most of a tile (dense entries, pixel mode, region tags: round 4)
     opts['dist_scale'] = float(opts.get('dist_scale', 1e-2)) * float(rs.choice([1.0, 1.0, 4.0, 10.0]))
+    # `smalleps`: every case with a small dist_eps -- the reference's border test (kernel.cu:747), not the distribution's tail,
+    # ends a face's reach there (the regime of the coverage kernel's box test: round 4's case 255)
+    if small_eps:
+        opts['dist_eps'] = float(small_rs.choice([1.0, 1.5, 3.0, 10.0, 30.0]))
     res, h, r = parity.compare(fv, tex, isz, opts)
     grad = np.random.RandomState(1).randn(B, 4, isz, isz).astype(np.float32)
     fails, _, _ = criteria.check_case(fv, tex, isz, opts, h, grad, oracle_f32=r)
