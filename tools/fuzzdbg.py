@@ -4,7 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import parity, scenes
-n_cases, seed, want = int(sys.argv[1]), int(sys.argv[2]), [int(v) for v in sys.argv[3:]]
+small_eps = 'smalleps' in sys.argv            # the draw of `fuzz_parity.py n seed smalleps`
+small_rs = np.random.RandomState(77)
+n_cases, seed, want = int(sys.argv[1]), int(sys.argv[2]), [int(v) for v in sys.argv[3:] if v != 'smalleps']
 rs = np.random.RandomState(seed)
 names = [n for n, _ in scenes.OPTION_MATRIX]
 for case in range(n_cases):
@@ -19,6 +21,8 @@ for case in range(n_cases):
     fv[..., :2] *= scale
     opts.pop('T', None); opts['T'] = T
     opts['dist_scale'] = float(opts.get('dist_scale', 1e-2)) * float(rs.choice([1.0, 1.0, 4.0, 10.0]))
+    if small_eps:
+        opts['dist_eps'] = float(small_rs.choice([1.0, 1.5, 3.0, 10.0, 30.0]))
     if case not in want:
         continue
     grad = np.random.RandomState(1).randn(B, 4, isz, isz).astype(np.float32)
@@ -37,6 +41,10 @@ for case in range(n_cases):
     if parity.reference_available():
         others += [('ref kernels', parity.run_reference(fv, tex, isz, opts, grad, np.float32)), ('ref fma build', parity.run_reference(fv, tex, isz, opts, grad, np.float32, variant='render_fma'))]
     for label, r in others:
+        for k in ('grad_faces', 'grad_textures'):
+            if k in r:
+                d = np.abs(h[k].astype(np.float64).reshape(r[k].shape) - r[k]); i = np.unravel_index(int(d.argmax()), d.shape)
+                print('   %s hip vs %-14s max |diff| %.3g at %s (hip %.6g, other %.6g)' % (k, label, d.max(), i, h[k].reshape(r[k].shape)[i], r[k][i]))
         d = np.abs(h['rgba'].astype(np.float64) - r['rgba'].reshape(h['rgba'].shape)); i = np.unravel_index(int(d.argmax()), d.shape)
         print('   rgba hip vs %-14s max |diff| %.3g at %s (hip %.6g, other %.6g); elements > 1e-5: %d' % (label, d.max(), i, h['rgba'][i], r['rgba'].reshape(h['rgba'].shape)[i], int((d > 1e-5).sum())))
     for (la, ra), (lb, rb) in ((others[0], others[1]),) + (((others[2], others[3]), (others[2], others[0])) if len(others) > 2 else ()):
