@@ -38,3 +38,21 @@ def test_random_shape_and_option_set(oracle_mod, native_lib, seed):
     h2 = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
     for k in ('rgba', 'aggrs_info'):
         assert np.array_equal(h[k], h2[k], equal_nan=True), (name, k)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_with_a_small_dist_eps_cull_exactly(native_lib, seed):
+    """The regime in which the reference's border test (kernel.cu:747), not the distribution's tail, ends a face's reach: the same draw
+    with dist_eps forced to 1 .. 30, forward only, several draws per seed.  Held to culled == all-pairs bit for bit -- the property the
+    coverage kernel's box test has to deliver (round 4: tools/fuzz_parity.py case 255); the all-pairs traversal is what the pin tests hold
+    to the reference's kernels.  (No comparison with the oracle here: on random slivers with a small dist_eps the reference's own two
+    builds differ on half the pixels)"""
+    rs = np.random.RandomState(5000 + seed)
+    for _ in range(4):
+        name, opts, fv, tex, isz = _draw(rs)
+        opts['dist_eps'] = float(rs.choice([1.0, 1.5, 3.0, 10.0, 30.0]))
+        opts['dist_scale'] = float(opts.get('dist_scale', 1e-2)) * float(rs.choice([1.0, 4.0, 10.0]))
+        a = parity.run_hip(fv, tex, isz, opts, None)
+        b = parity.run_hip(fv, tex, isz, dict(opts, cull=0), None)
+        for k in ('rgba', 'aggrs_info'):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (name, opts, fv.shape, isz, k)
