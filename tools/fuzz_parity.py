@@ -1,7 +1,11 @@
 """Randomised HIP-vs-oracle check over shapes the fixed suites do not enumerate (run on the GPU box):
-    python tools/fuzz_parity.py [n_cases] [seed] [smalleps]
+    python tools/fuzz_parity.py [n_cases] [seed] [smalleps] [ref]
 Random batch size, face count (around the 64-face chunk boundaries), image size (odd sizes, sizes with empty 64x64
-super-tiles), texture layout and option set; the acceptance rule of tests/criteria.py; also culled == all-pairs."""
+super-tiles), texture layout and option set; the acceptance rule of tests/criteria.py; also culled == all-pairs.
+`ref` (needs oracle/_ref): additionally the `exact` build variant against the reference's OWN kernels wherever the reference's
+two builds (contraction off / on) agree with each other to 1e-6 -- there nothing about the scene is ill-conditioned, the
+variant calls the reference's libm functions, and a difference above 1e-5 is a structural defect (culling, coverage), not
+noise: the detector that would have flagged round 4's case 255 without a second look."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -10,7 +14,8 @@ import criteria, parity, scenes
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-small_eps = len(sys.argv) > 3 and sys.argv[3] == 'smalleps'
+small_eps = 'smalleps' in sys.argv[3:]
+with_ref = 'ref' in sys.argv[3:] and parity.reference_available() and parity.reference_available('render_fma')
 small_rs = np.random.RandomState(77)           # (its own stream: the draw of everything else stays the plain campaign's)
 names = [n for n, _ in scenes.OPTION_MATRIX]
 bad = 0
@@ -42,6 +47,16 @@ for case in range(n_cases):
     same = all(np.array_equal(h[k], h2[k], equal_nan=True) for k in ('rgba', 'aggrs_info'))
     if not same:
         fails.append('culled != all-pairs')
+    if with_ref and parity.split_options(opts)[1]['texel_mode'] == 0:        # (the reference has no clamped texel mode)
+        r1 = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
+        r2 = parity.run_reference(fv, tex, isz, opts, grad, np.float32, variant='render_fma')
+        he = parity.run_hip(fv, tex, isz, opts, grad, variant='exact')
+        a1 = r1['rgba'].astype(np.float64).reshape(he['rgba'].shape)
+        agree = np.abs(a1 - r2['rgba'].reshape(he['rgba'].shape)) <= 1e-6
+        viol = agree & (np.abs(he['rgba'] - a1) > 1e-5)
+        if viol.any():
+            fails.append('STRUCTURAL: exact variant differs from the reference kernels on %d rgba elements where the reference\'s two builds agree (of %d), first %s'
+                         % (int(viol.sum()), int(agree.sum()), tuple(int(v) for v in np.argwhere(viol)[0])))
     status = 'ok' if not fails else 'FAIL ' + '; '.join(fails)
     bad += bool(fails)
     print('%3d %-24s B=%d nf=%3d is=%3d T=%d scale=%.2f  rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, res['rgba']['max_rel'], status), flush=True)
