@@ -56,6 +56,11 @@ CONFIGS = {
 }
 
 
+def _active_variant():
+    from gendr_amd import _native
+    return _native._active
+
+
 def algorithmic_bytes(P, nf, T):
     """every tensor crossing the Function boundary touched once.
     forward: read faces 36 nf + textures 12 T nf, write RGBA 16 P;
@@ -463,8 +468,9 @@ def fast_variant_extra(args, cfg, rank, world, dev, dist):
     order, skip tests and culling with the per-pair arithmetic at hardware accuracy and contraction on).  Never the
     headline: it does not reproduce the reference's rounding; its parity standing is quoted from the committed table."""
     from gendr_amd import _native, build
-    if not os.path.exists(build.lib_path('fast')):
-        return {'error': 'libgendr_hip_fast.so is not built'}
+    if not os.path.exists(build.lib_path('fast')) or build.needs_build('fast'):
+        return {'skipped': 'libgendr_hip_fast.so is built on request only since round 5 (python -m gendr_amd.build fast); round 4 measured '
+                           '+7.7 % at this config on the driver\'s box (BENCH_r04.json)'}
     with _native.use_variant('fast'):
         wl = Workload(args, cfg, rank, world, dev, args.scaling)
         a = argparse.Namespace(**dict(vars(args), steps=max(10, args.steps), warmup=3))
@@ -472,7 +478,7 @@ def fast_variant_extra(args, cfg, rank, world, dev, dist):
     out = {'value': wl.global_batch * a.steps / m['elapsed'], 'unit': 'frames/s', 'ms_per_step': m['elapsed'] / a.steps * 1e3,
            'launch': m['launch'], 'steps': a.steps,
            'kernel_ms': {'forward_phase': m['fwd_ms'], 'backward_phase': m['bwd_ms']},
-           'what': '-DGENDR_FAST_MATH=1 -ffp-contract=fast: float reciprocals (<= 1 ulp) instead of exactly rounded quotients, v_sqrt_f32, '
+           'what': '-DGENDR_FAST_MATH=1 -ffp-contract=on: float reciprocals (<= 1 ulp) instead of exactly rounded quotients, v_sqrt_f32, '
                    '2^x-based exp, float instead of double sub-expressions, contraction on; formulas, operation order, skip tests and '
                    'culling unchanged'}
     try:
@@ -682,7 +688,11 @@ def main():
                                                                           else 'no data-path collective'),
                        'backend': (backend if dist is not None else None),
                        'launch': m['launch'],
-                       'cull': os.environ.get('GENDR_CULL', '1') != '0'},
+                       'cull': os.environ.get('GENDR_CULL', '1') != '0',
+                       # the build variant that ran (gendr_amd/build.py): 'default' is the shipped library -- since round 5 within a
+                       # flat 1e-5 of the reference's own kernels on every BASELINE configuration (tests/test_gpu_reference_pin.py,
+                       # tests/golden/reference/pin_table.json: no exception rows)
+                       'variant': _active_variant()},
         }
         if m['bwd_ms'] is not None:
             # The longest single kernel is the backward render kernel; the events around the backward native call
@@ -694,7 +704,7 @@ def main():
             # Profiler figures of the same kernels: HBM traffic (separate rocprofv3 --pmc passes of FETCH_SIZE / WRITE_SIZE) and
             # the VALU occupation (SQ_ACTIVE_INST_VALU), read from profiles/pmc_<config>.json -- but only if that file was
             # collected on THESE kernel sources (it carries their hash): a stale file yields null, not a number.
-            traffic, valu_busy, source = None, None, None
+            traffic, valu_busy, source, lane_frac = None, None, None, None
             pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.config)
             if os.path.exists(pmc_path):
                 try:
@@ -702,7 +712,10 @@ def main():
                     pmc = json.load(open(pmc_path))
                     if pmc.get('kernel_sha') == _b.source_sha():
                         traffic = pmc.get('hbm_bytes_per_launch', {}).get(dom)
-                        valu_busy = pmc.get('valu_busy', {}).get(dom)
+                        # (calibrated against a pure-VALU kernel of known occupation collected in the same profile run, when the file
+                        # has it: tools/micro/valucal.hip)
+                        valu_busy = pmc.get('valu_busy_calibrated', pmc.get('valu_busy', {})).get(dom)
+                        lane_frac = pmc.get('useful_lane_frac', {}).get(dom)
                         # traffic is quoted PER LAUNCH of this line's batch: the counter passes record the batch they ran at
                         # (C4 / C5 counters of one batch were set beside the algorithmic bytes of another); a pass at
                         # another batch is scaled linearly (the traffic is per frame to a few percent) and the line says so
@@ -721,7 +734,9 @@ def main():
                 except Exception:
                     traffic = None
             out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'valu_busy': valu_busy, 'traffic_source': source,
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'valu_busy': valu_busy,
+                               # share of the issued vector lane-slots that did work: SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)
+                               'useful_lane_frac': lane_frac, 'traffic_source': source,
                                'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
                                'note': 'VALU-bound path (SURVEY.md H2: report the VALU occupation beside the HBM fraction); '
                                        'whole-op fraction on rank 0 = %.4f'
@@ -760,9 +775,8 @@ def main():
                     extra['caller_shapes'] = caller_shapes_extra(dev)
                 except Exception as e:
                     extra['caller_shapes'] = {'error': '%s: %s' % (type(e).__name__, e)}
-            sweep = os.path.join(ROOT, 'profiles', 'r04_%s_batch_sweep.json' % args.config)
-            if not os.path.exists(sweep):
-                sweep = os.path.join(ROOT, 'profiles', 'r03_%s_batch_sweep.json' % args.config)
+            sweep = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_%s_batch_sweep.json' % (r, args.config)) for r in (5, 4, 3))
+                          if os.path.exists(q)), '')
             if os.path.exists(sweep):
                 try:
                     from gendr_amd import build as _b

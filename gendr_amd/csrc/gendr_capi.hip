@@ -64,10 +64,12 @@ const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_K(kGaussian,    kEinstein,      1, 1, kTexSurface1, w6, wa),   // C3 (backward: 4 waves, less spill)
     GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 1, 0, kTexSurface1),   // C4
     GENDR_SPECIALISE_K(kGamma,       kYager,         1, 0, kTexVertex, C5F, C5B),   // C5
-    GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // opt_shape / train_reconstruction soft renderer (hard RGB)
-    GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),   // opt_shape hard renderer (opt_shape.py:148-159)
+    GENDR_SPECIALISE_OCC(kUniform,   kProbabilistic, 0, 0, kTexSurface1),   // train_reconstruction.py:181-196,557 (uniform, hard RGB)
+    GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 0, 0, kTexSurface1),   // opt_shape.py:134-145 soft renderer (its default --dist-func logistic, hard RGB)
+    GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),   // opt_shape.py:146-157 hard renderer (it passes dist_squared=True: dead for dist_func 0, see pick_kernel)
     // alpha-only (silhouette) kernels, SURVEY f-4: what opt_shape / train_reconstruction actually consume
     GENDR_SPECIALISE_K(kUniform,     kProbabilistic, kRgbNone, 0, kTexSurfaceN, w6, wa),
+    GENDR_SPECIALISE_K(kLogistic,    kProbabilistic, kRgbNone, 0, kTexSurfaceN, w6, wa),
     GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     kRgbNone, 0, kTexSurfaceN),
 };
 
@@ -102,9 +104,12 @@ const KernelEntry& pick_generic(const gendr_params* p, int texm, bool silhouette
 const KernelEntry& pick_kernel(const gendr_params* p, int texm, bool silhouette = false)
 {
     const int rgb = silhouette ? kRgbNone : p->aggr_rgb_func;
+    // dist_squared does nothing for dist_func 0: the fragment is the inside test (kernel.cu:762-764; soft_fragment()) and there is
+    // no distance gradient (:375-376) -- the reference's opt_shape hard renderer passes True (opt_shape.py:149)
+    const int sq = (p->dist_squared && p->dist_func != kHeaviside) ? 1 : 0;
     for (const KernelEntry& e : kSpecialised) {
         if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == rgb &&
-            e.key.sq == (p->dist_squared ? 1 : 0) && e.key.texm == texm)
+            e.key.sq == sq && e.key.texm == texm)
             return e;
     }
     return pick_generic(p, texm, silhouette);
@@ -199,7 +204,9 @@ Workspace workspace_layout(int B, int nf, int T, const gendr_params* p)
     w.ordered = (long)tiles <= kOrderTilesMax && tiles >= 16 && w.ent_cap8 > 0;
     // faces with a loose cull box, large images (loose_faces_kernel): [flag B*nf i32][box B*nf 4 x i32][list per image B x 16 i32]
     w.loose_off = w.sorted_off + (w.ordered ? align256(tiles * sizeof(int4)) : 0);
-    w.loose_lists = (long)w.tiles_x * w.tiles_x >= GENDR_LOOSE_MIN_TILES;
+    // (loose_faces == 2 forces the list path at any image size: it is the default at 1024^2 and more -- BASELINE config 5 -- and
+    // the parity suites run at 32 ... 768 pixels: ADVICE r4)
+    w.loose_lists = (long)w.tiles_x * w.tiles_x >= GENDR_LOOSE_MIN_TILES || p->loose_faces == 2;
     w.control_off = w.loose_off + (w.loose_lists ? align256((size_t)B * nf * sizeof(int)) + align256((size_t)B * nf * sizeof(int4)) + align256((size_t)B * kLooseList * sizeof(int)) : 0);
     w.ncontrol = kCtlInts;
     // deterministic backward: [count + list of the deferred faces][their band sums]
@@ -318,8 +325,11 @@ int render_blocks(int total_blocks, int split_items = 0)
 // Queried once per kernel and device.
 int resident_per_queue(render_kernel_t k)
 {
+    // (one slot per render kernel of the dispatch tables and device: ~60 kernels; a thread that fills the cache keeps querying
+    // the kernels that did not fit -- ADVICE r4: 16 slots were fewer than a test session's option sets)
     struct Slot { render_kernel_t k; int dev; int v; };
-    static thread_local Slot cache[16];
+    constexpr int kSlots = 256;
+    static thread_local Slot cache[kSlots];
     static thread_local int used = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -331,7 +341,7 @@ int resident_per_queue(render_kernel_t k)
     (void)hipGetLastError();
     const int v = per_cu * cus / 8;
     if (getenv("GENDR_DEBUG")) fprintf(stderr, "gendr: resident_per_queue per_cu %d cus %d -> %d\n", per_cu, cus, v);
-    if (used < 16) cache[used++] = Slot{k, dev, v};
+    if (used < kSlots) cache[used++] = Slot{k, dev, v};
     return v;
 }
 
@@ -540,7 +550,6 @@ int gendr_silhouette_forward(const float* faces, float* alpha, void* workspace, 
     a.iou_sums = iou_sums;
     a.p.background_from_buffer = 0;
     const KernelEntry& k = pick_kernel(p, texm, true);
-    a.resident_q = resident_per_queue(k.fwd);
     hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, true))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
@@ -567,7 +576,6 @@ int gendr_silhouette_backward(const float* alpha, const void* workspace, const f
     a.p.background_from_buffer = 0;
     if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, kSilT, p, true, stream);
     const KernelEntry& k = pick_kernel(p, texm, true);
-    a.resident_q = resident_per_queue(k.bwd);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, true))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
@@ -652,7 +660,7 @@ int gendr_span_read(unsigned long long* dst, int kernel, int n)
 int gendr_selftest(int what, unsigned long long* report16, void* stream)
 {
     if (!report16) return GENDR_E_NULL;
-    if (what < 0 || what > 2) return GENDR_E_SHAPE;
+    if (what < 0 || what > 4) return GENDR_E_SHAPE;
     if (hipMemsetAsync(report16, 0, 16 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return GENDR_E_LAUNCH;
     hipLaunchKernelGGL(selftest_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, what, report16);
     return check_launch();
@@ -778,7 +786,6 @@ int gendr_forward(const float* faces, const float* textures, float* rgba, float*
     a.rgba = rgba;
     a.aux = aggrs_info;
     const KernelEntry& k = pick_kernel(p, texm);
-    a.resident_q = resident_per_queue(k.fwd);
     hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, false))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
@@ -805,7 +812,6 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.p.background_from_buffer = 0;
     if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, T, p, false, stream);
     const KernelEntry& k = pick_kernel(p, texm);
-    a.resident_q = resident_per_queue(k.bwd);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, false))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }

@@ -295,7 +295,6 @@ struct RenderArgs {
     int*   det_count;           // deterministic backward: number of deferred (large-box) faces, their list, their band sums
     int*   det_list;
     float* det_partial;
-    int resident_q;             // waves of the launched render kernel the chip holds at once, per tile queue (sub-tile split)
     // faces whose cull box is loose, images of kLooseMinTiles tiles and more (see loose_faces_kernel): per face a flag and the
     // box of its live pixels (columns lo / hi, rows lo / hi; empty: lo > hi), per image a list of kLooseList ints:
     // (loose_stamp << 4 | entries), then the faces.  NULL: no lists (smaller images: the coverage kernel alone deals with them)
@@ -2915,18 +2914,28 @@ __global__ __launch_bounds__(kThreads) void det_reduce_kernel(const RenderArgs a
 // out[2..] = up to 14 offending bit patterns.
 __global__ __launch_bounds__(256) void selftest_kernel(int what, unsigned long long* out)
 {
-    const unsigned lo = __float_as_uint(0x1p-96f), hi = __float_as_uint(0x1p+96f);
+    // what 0..2: sqrt_rn, rcp_rn(+x), rcp_rn(-x) on every float of [2^-96, 2^96];  what 3 / 4: norm_cdf(u) / norm_cdf(-u) against the
+    // library's double normcdf rounded to float -- what the reference's kernel compiled for this platform computes -- on every
+    // float u of [0, 6] (the polynomial's whole range and what lies beyond it)
+    const bool ncdf = what >= 3;
+    const unsigned lo = ncdf ? 0u : __float_as_uint(0x1p-96f), hi = ncdf ? __float_as_uint(6.f) : __float_as_uint(0x1p+96f);
     unsigned long long bad = 0, n = 0;
     for (unsigned long long u = (unsigned long long)lo + blockIdx.x * 256ull + threadIdx.x; u <= hi; u += (unsigned long long)gridDim.x * 256ull) {
         float x = __uint_as_float((unsigned)u);
-        if (what == 2) x = -x;
-        const float got = what == 0 ? sqrt_rn(x) : rcp_rn(x);
-        const float want = what == 0 ? sqrtf(x) : 1.f / x;
+        if (what == 2 || what == 4) x = -x;
+        float got, want;
+        if (ncdf)           { got = norm_cdf(x); want = (float)normcdf((double)x); }
+        else if (what == 0) { got = sqrt_rn(x); want = sqrtf(x); }
+        else                { got = rcp_rn(x); want = 1.f / x; }
         n++;
-        if (__float_as_uint(got) != __float_as_uint(want)) {
+        // (norm_cdf: values at or below 5e-7 are equal for this purpose -- the pair is skipped at 1e-6, kernel.cu:784, whatever they are)
+        if (__float_as_uint(got) != __float_as_uint(want) && !(ncdf && got <= 5e-7f && want <= 5e-7f)) {
             bad++;
             const unsigned long long slot = atomicAdd(out + 15, 1ull);
-            if (slot < 13) out[2 + slot] = u;
+            if (slot < 12) out[2 + slot] = u;
+            // the largest difference in units of the last place
+            const long long d = (long long)__float_as_uint(got) - (long long)__float_as_uint(want);
+            atomicMax(out + 14, (unsigned long long)(d < 0 ? -d : d));
         }
     }
     atomicAdd(out + 0, bad);

@@ -18,7 +18,7 @@
 
 #define GENDR_HD __host__ __device__ __forceinline__
 
-// Build variant "fast" (gendr_amd/build.py VARIANTS: -DGENDR_FAST_MATH=1 -ffp-contract=fast; libgendr_hip_fast.so).  The
+// Build variant "fast" (gendr_amd/build.py VARIANTS: -DGENDR_FAST_MATH=1 -ffp-contract=on; libgendr_hip_fast.so).  The
 // default build reproduces the reference's ROUNDING operation by operation (correctly rounded quotients through double
 // reciprocals, correctly rounded sqrt / reciprocal, the library's expf, no contraction); the fast build keeps the
 // reference's FORMULAS, operation order, fold order, skip tests and culling, and computes the per-pair arithmetic the way a
@@ -166,6 +166,14 @@ GENDR_HD float rcp_rn(float x)
 #ifndef GENDR_EXACT_GRADIENT
 #define GENDR_EXACT_GRADIENT 0
 #endif
+// The forward-side forms of the gaussian and gamma families (norm_cdf, the power of gamma's CDF) and their densities: see
+// norm_cdf().  GENDR_EXACT_CDF / GENDR_EXACT_PDF = 1: what the reference's kernel compiled for this platform calls.
+#ifndef GENDR_EXACT_CDF
+#define GENDR_EXACT_CDF GENDR_EXACT_GRADIENT
+#endif
+#ifndef GENDR_EXACT_PDF
+#define GENDR_EXACT_PDF GENDR_EXACT_GRADIENT
+#endif
 GENDR_HD float grad_rcp(float b)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
@@ -218,16 +226,79 @@ GENDR_HD float quiet_nan() { return __builtin_nanf(""); }
 
 // normal CDF of a float argument (kernel.cu:293: `normcdf(sign * x / scale)` on a float).  CUDA resolves that call to its
 // float overload; HIP has no normcdf(float), so the reference's kernel compiled for THIS platform (oracle/build_ref.py)
-// promotes to normcdf(double) and rounds the result.  Default build and host: 0.5 erfc(-u / sqrt 2) in float, the form the
-// CPU restatement uses (HIP's normcdff was measured 3 % slower at BASELINE config 3 and is no closer to either reference);
-// `exact` build: the double function rounded to float -- what the pin build of the reference computes here, so that the exact
-// variant agrees with it to 1e-5 on the gaussian option sets too (round 4: the three float forms -- normcdff, 0.5 erfcf(-u /
-// sqrt 2), double rounded -- differ in the last bit, which the saturated einstein partial (1 - A^2) / (1 - D^2) amplifies to
-// 1e-3 of a face-gradient element).
+// promotes to normcdf(double) and rounds the result -- the pin.  Round 4's default build evaluated 0.5 erfcf(-u / sqrt 2) in
+// float.  A last-bit difference of ANY fragment of a pixel -- also a tiny one of a face that only grazes it -- can move the last
+// bit of the pixel's folded alpha A, and the reference's saturated partials ((1 - A^2) / (1 - D^2) with A one or two units of
+// the last place below 1) turn that into a factor: BASELINE config 3 missed the flat 1e-5 against the reference's kernels on
+// 2.5 percent of its face-gradient elements (max 1.3e-3), and a first round-5 attempt that made only the D >= 1/2 side exact
+// still did.  Calling the library's normcdf(double) per pair fixes it and costs the forward kernel a factor 2.4 (measured:
+// 0.194 -> 0.459 ms at config 3; ~1000 wave instructions per batch, all of the library's argument ranges under divergence).
+// Device code of the default build instead, ONE branch-free path for |u| < 5.625:
+//     Q(x) = Phi(-x) = e^(-x^2 / 2) g(x),   x = |u|,      D = u < 0 ? Q : 1 - Q,   rounded to float once,
+//   * x^2 / 2 is exact in double (x is a float); e^y by y = k ln 2 + r, |r| <= ln 2 / 2, a degree-13 Taylor polynomial and
+//     v_ldexp_f64;
+//   * g(x) = Phi(-x) e^(x^2 / 2) (Mills' ratio over sqrt(2 pi): smooth, 0.5 ... 0.07) by one polynomial of degree 30 on
+//     [0, 5.625] (Chebyshev interpolant converted to the monomial basis in 70-digit arithmetic, tools/normcdf_coef.py; Horner in
+//     double is stable here).  Relative error of Q < 2^-50 against 60-digit values.
+//   A float result differs from the library's double result rounded only where Phi lies within ~2^-50 (relative) of a
+//   rounding midpoint: gendr_selftest(3) compares the two for EVERY float of [-6, 6] on the GPU
+//   (tests/test_gpu_exact_math.py holds the count of differing inputs -- each by one unit of the last place).
+//   * u >= 5.625: Q < 2^-25, exactly 1.  u <= -5.625: Phi < 1e-8, far below the 1e-6 at which the pair is skipped (:784):
+//     the float form.
+//   The 45 double constants are materialised in SCALAR registers where they are used (sconst(): a volatile asm the loop
+//   optimiser cannot hoist): left to itself the compiler keeps them in 90 vector registers across the batch loop and spills
+//   (measured: 30 scratch reloads per batch, forward 0.194 -> 0.401 ms).
+// `exact` build (GENDR_EXACT_CDF): the library's double function rounded, for every argument.  Host: the float form.
+#ifndef GENDR_NORMCDF_POLY
+#define GENDR_NORMCDF_POLY 1
+#endif
+constexpr double kNormQEnd = 5.625;
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double sconst(double c) { asm volatile("" : "+s"(c)); return c; }
+#else
+inline double sconst(double c) { return c; }
+#endif
+GENDR_HD double norm_q(double x)             // Q(x) = Phi(-x) on [0, kNormQEnd], relative error < 2^-50
+{
+    constexpr double g[31] = {
+        0.12830188067911721, -0.10713724028835606, 0.083707806232990997,
+        -0.061776828075667381, 0.043369365984936591, -0.029121180260832224,
+        0.018784229226290805, -0.011680985402171174, 0.0070234710631495905,
+        -0.0040935184923098222, 0.0023176382985891928, -0.0012770442848394634,
+        0.00068593819084243537, -0.00035967374710264654, 0.00018434426003539211,
+        -9.245390998209764e-05, 4.5424960960400369e-05, -2.1896313100973583e-05,
+        1.0350492914507299e-05, -4.7799949982060067e-06, 2.1831155246446762e-06,
+        -1.0166169632747425e-06, 4.4682677084580456e-07, -1.5632209228437453e-07,
+        6.8643198950753235e-08, -5.6374486597669725e-08, 2.2602849241977347e-08,
+        3.8511174054904546e-09, -1.29523774689231e-09, -3.2409135017486482e-09,
+        1.2443686235586019e-09,
+    };
+    constexpr double kInvFact[14] = {1., 1., 1. / 2, 1. / 6, 1. / 24, 1. / 120, 1. / 720, 1. / 5040, 1. / 40320, 1. / 362880,
+                                     1. / 3628800, 1. / 39916800, 1. / 479001600, 1. / 6227020800.};
+    const double y = -0.5 * (x * x);                                     // exact
+    const double k = __builtin_rint(y * sconst(1.4426950408889634));     // log2(e)
+    double r = __builtin_fma(-k, sconst(0.6931471805599453094), y);
+    r = __builtin_fma(-k, sconst(2.3190468138462996e-17), r);
+    double e = sconst(kInvFact[13]);
+#pragma unroll
+    for (int n = 12; n >= 0; n--) e = __builtin_fma(e, r, sconst(kInvFact[n]));
+    const double t = __builtin_fma(x, sconst(2. / kNormQEnd), -1.);
+    double q = sconst(g[30]);
+#pragma unroll
+    for (int n = 29; n >= 0; n--) q = __builtin_fma(q, t, sconst(g[n]));
+    return __builtin_ldexp(e, (int)k) * q;
+}
 GENDR_HD float norm_cdf(float u)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && GENDR_EXACT_GRADIENT
+#if defined(__HIP_DEVICE_COMPILE__) && GENDR_EXACT_CDF
     return (float)normcdf((double)u);
+#elif defined(__HIP_DEVICE_COMPILE__) && GENDR_NORMCDF_POLY
+    if (u >= (float)kNormQEnd) return 1.f;
+    if (u > -(float)kNormQEnd) {
+        const double q = norm_q((double)__builtin_fabsf(u));
+        return (float)(u < 0.f ? q : 1. - q);
+    }
+    return 0.5f * erfcf(-u * 0.70710678118654752440f);       // (NaN ends up here and stays NaN)
 #else
     return 0.5f * erfcf(-u * 0.70710678118654752440f);
 #endif
@@ -303,7 +374,7 @@ template <> struct Dist<kWigner> {
 template <> struct Dist<kGaussian> {
     static GENDR_HD float cdf(float sign, float x, const DistParams& d) { return norm_cdf(div_by(sign * x, d.rscale)); }   // :292-293
     static GENDR_HD float pdf(float, float x, const DistParams& d) {                                     // :404-405 (exp in double)
-#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_PDF
         // gradient side (see grad_div): the density to fp32 accuracy, exp in float instead of double
         const float q = div_by(x, d.rscale);
         return (float)(d.rscale * 0.3989422804014327) * exp_f(-0.5f * q * q);
@@ -414,12 +485,14 @@ template <bool REV> struct GammaFamily {                                        
             factor *= d.gamma_r ? div_by(xr, d.gamma_r[i - 1]) : xr / (d.shape + i);
             kummers += factor;
         }
-#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
-        // (the `exact` build variant calls powf for every shape, like the reference: the parity artefact)
-        // shape 1 and 2 (2: the setting of BASELINE config 5): the power is the operand resp. one multiply -- the
-        // correctly rounded value, which the library's powf (~100 instructions) reaches to within an ulp
+#if GENDR_FAST_DEV
+        // fast variant only: shape 1 and 2 without a power
         const float xp = d.shape == 2.f ? xr * xr : (d.shape == 1.f ? xr : powf(xr, d.shape));
 #else
+        // powf for every shape, as the reference's kernel calls it (:309).  Round 4's default build wrote xr * xr for shape 2 (the
+        // correctly rounded square, which the library's powf only reaches to within an ulp): that last bit, through gamma_rev's
+        // 1 - y and the saturated t-conorm partials, kept BASELINE config 5 from a flat 1e-5 against the reference's kernels on
+        // 15 percent of its face-gradient elements (max 4.7e-3).  Measured cost of the call at config 5: forward +5 %, backward +6 %.
         const float xp = powf(xr, d.shape);
 #endif
         const float y = xp * exp_f(div_by(-xs, d.rscale)) * kummers;
@@ -427,7 +500,7 @@ template <bool REV> struct GammaFamily {                                        
     }
     static GENDR_HD float pdf(float sign, float x, const DistParams& d) {                                // explicit double in the reference
         if (d.shape < 0.f) return quiet_nan();
-#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_GRADIENT
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_PDF
         // gradient side (see grad_div): shape 1 and 2 (2: BASELINE config 5) need no power -- xs^(shape - 1) is 1 resp.
         // xs -- and the density to fp32 accuracy only a float exponential, instead of ~400 double-precision
         // instructions per pair.  Other shapes keep the double evaluation (a float power would underflow where the

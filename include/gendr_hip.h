@@ -98,8 +98,11 @@ typedef struct gendr_params {
                                       in every tile of their image.  With this on, the binning stage of gendr_forward /
                                       gendr_face_setup evaluates such a face on the pixels of its image (the render kernels' own pair
                                       functions) and lists it only in the tiles that hold a pixel which can contribute at all.
-                                      Results are the same either way.  0 (default) and 1: on (since round 4 it is part of the binning
-                                      kernel and costs nothing where no face is flagged); -1: off. */
+                                      Results are the same either way.  0 (default) and 1: on (since round 4 it is part of the coverage
+                                      kernel and costs nothing where no face is flagged; in images of 1024^2 and more a launch of its
+                                      own first narrows the boxes of such faces, per-image lists in the workspace); -1: off;
+                                      2: on, with that launch and its lists at EVERY image size (what 1024^2 and more take by default:
+                                      lets small test images exercise it). */
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward
@@ -252,8 +255,11 @@ int gendr_project_faces_backward(const float* vertices, const int* face_index, c
 
 /* Self-test of the short correctly-rounded forms the pair math uses for sqrtf(x) and 1.f / x (gendr_math.h: sqrt_rn,
  * rcp_rn): compares them with the compiler's IEEE expansions for EVERY float bit pattern in [2^-96, 2^96].
- *   what: 0 sqrt, 1 reciprocal of +x, 2 reciprocal of -x.   report16 (device, 16 x u64): [0] mismatches, [1] values
- *   tested, [2..14] offending bit patterns. */
+ *   what: 0 sqrt, 1 reciprocal of +x, 2 reciprocal of -x; 3 / 4: the normal CDF of the gaussian distribution at +u / -u
+ *   (gendr_math.h: norm_cdf, e^(-u^2/2) times a degree-30 polynomial, in double) against the library's normcdf(double) rounded
+ *   to float -- what the reference's kernel.cu:293 computes when compiled for this platform -- for every float u in [0, 6].
+ *   report16 (device, 16 x u64): [0] mismatches, [1] values tested, [2..13] offending bit patterns, [14] largest difference
+ *   in units of the last place. */
 int gendr_selftest(int what, unsigned long long* report16, void* stream);
 
 const char* gendr_error_string(int code);

@@ -95,9 +95,12 @@ def render(fv, tex, image_size, p, grad=None, dtype=np.float32, variant='render'
 
     pad_textures: the reference's texel index can run past a face's texels (kernel.cu:153-176 with a clipped weight of
     exactly 1: index T instead of T - 1), i.e. into the next face's -- and for the last face of the tensor past the end of
-    the tensor, which is undefined behaviour.  The textures therefore live at the front of a larger buffer whose tail
-    repeats the tensor's last texel, so that such a read stays inside this allocation and returns what the restatement
-    defines for it (the face's own clamped texel; identical for T = 1, where the only texel is the last).
+    the tensor, which is undefined behaviour.  The overflowing index is exactly T -- w = (0, 1, 0): wy = R, wx = 0, index
+    wy R + wx (:179-183); the mirrored branch cannot overflow -- so the read lands on the first texel behind the tensor.  The
+    textures therefore live at the front of a larger buffer whose tail repeats what the restatement and the product DEFINE for
+    that read: the last face's own texel at the clamped index, (R - 1) R = T - R (the only texel for T = 1; round 5: the tail
+    used to repeat the tensor's last texel, T - 1, which is the same thing only for R = 1 -- found by the reference-arbitrated
+    fuzz test on T = 4 / 9 draws).
     background: three floats (default: p.background, i.e. rounded to float as functional/renderer.py:147-149 does)."""
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     scalar = 'float' if dtype == np.float32 else 'double'
@@ -107,7 +110,9 @@ def render(fv, tex, image_size, p, grad=None, dtype=np.float32, variant='render'
     faces = torch.from_numpy(np.ascontiguousarray(fv, dtype)).reshape(B, nf, 9).to(device)
     tex_t = torch.from_numpy(np.ascontiguousarray(tex, dtype)).to(device)
     if pad_textures:
-        store = tex_t.reshape(-1)[-3:].repeat(tex_t.numel() // 3 + 1366)[:tex_t.numel() + 4098].contiguous()
+        R = int(np.sqrt(T)) if int(p.texture_type) == 0 else 1
+        own = tex_t.reshape(-1, 3)[tex_t.numel() // 3 - (R if int(p.texture_type) == 0 else 1)]       # last face, texel T - R
+        store = own.repeat(tex_t.numel() // 3 + 1366)[:tex_t.numel() + 4098].contiguous()
         store[:tex_t.numel()] = tex_t.reshape(-1)
         textures = store[:tex_t.numel()].view(B, nf, T, 3)
     else:

@@ -57,8 +57,10 @@ def one(key, fv, tex, isz, opts, grad, variants, report, table):
 
 
 def main():
-    from gendr_amd import build
-    variants = [v for v in ('default', 'exact', 'fast') if os.path.exists(build.lib_path(v))]
+    from gendr_amd import build, _native
+    # (PIN_VARIANTS=default,exact,<scratch name>: A/B libraries copied to gendr_amd/libgendr_hip_<name>.so)
+    names = os.environ.get('PIN_VARIANTS', 'default,exact,fast').split(',')
+    variants = [v for v in names if os.path.exists(_native.variant_path(v))]
     try:
         head = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:

@@ -215,23 +215,30 @@ def test_loose_face_boxes_change_nothing(native_lib, name, opts):
         grad = np.random.RandomState(4).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
         on = parity.run_hip(fv, tex, isz, dict(opts, loose_faces=1), grad)
         off = parity.run_hip(fv, tex, isz, dict(opts, loose_faces=-1), grad)
+        # loose_faces = 2: the per-image lists + loose_faces_kernel + the binning kernel narrowing by the live pixels' box -- the path
+        # images of 1024^2 and more (BASELINE config 5) take by default, forced onto these small images
+        lists = parity.run_hip(fv, tex, isz, dict(opts, loose_faces=2), grad)
         allp = parity.run_hip(fv, tex, isz, dict(opts, cull=0))
         for k in ('rgba', 'aggrs_info'):
             assert np.array_equal(on[k], off[k], equal_nan=True), (name, maker.__name__, k)
             assert np.array_equal(on[k], allp[k], equal_nan=True), (name, maker.__name__, k, 'all pairs')
+            assert np.array_equal(lists[k], allp[k], equal_nan=True), (name, maker.__name__, k, 'list path vs all pairs')
         for k in ('grad_faces', 'grad_textures'):
             scale = max(1e-30, float(np.abs(off[k]).max()))
             assert float(np.abs(on[k] - off[k]).max()) <= 2e-5 * scale, (name, maker.__name__, k)
+            assert float(np.abs(lists[k] - off[k]).max()) <= 2e-5 * scale, (name, maker.__name__, k, 'list path')
 
 
-def test_loose_faces_survive_graph_replay(native_lib):
-    """Loose faces are resolved inside the coverage kernel (round 4; round 3 kept per-image lists that a replayed graph -- same
-    kernel arguments, same workspace, over and over -- could make grow): forty replays of a captured forward call return the
-    first call's image."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_loose_faces_survive_graph_replay(native_lib, mode):
+    """Loose faces are resolved inside the coverage kernel (mode 1); images of 1024^2 and more -- and mode 2 at any size -- also keep
+    per-image lists in the workspace that the binning kernel empties after use, since a replayed graph (same kernel arguments, same
+    workspace, over and over) would otherwise make them grow: forty replays of a captured forward call return the first call's
+    image."""
     from gendr_amd.functional import renderer as R
     fv, tex = scenes.slivers()
     isz = 64
-    o, extra = parity.split_options(dict(loose_faces=1))
+    o, extra = parity.split_options(dict(loose_faces=mode))
     p = parity.hip_params(isz, o, extra)
     Bn, nf = fv.shape[:2]
     faces = torch.from_numpy(fv).reshape(Bn, nf, 9).cuda().contiguous()

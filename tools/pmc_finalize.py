@@ -1,6 +1,9 @@
 """Stamps a traffic summary (tools/traffic_summary.py) with the kernel sources' hash and adds the VALU occupation of every
-kernel:   python tools/pmc_finalize.py <pmc_cfg.json> <dir of the SQ counter pass with SQ_ACTIVE_INST_VALU> <kernel_stats.csv>
-valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles, MI355X_MICROARCH.md) * 4 / (1024 SIMDs * average kernel duration * 2.4 GHz)."""
+kernel:   python tools/pmc_finalize.py <pmc_cfg.json> <dir of the SQ counter pass with SQ_ACTIVE_INST_VALU> <kernel_stats.csv> [sq batch] [dir of the calibration pass]
+valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles, MI355X_MICROARCH.md) * 4 / (1024 SIMDs * average kernel duration * 2.4 GHz);
+valu_busy_calibrated = that divided by what the same expression reads for tools/micro/valucal.hip -- a kernel whose vector ALUs are
+occupied 100 % by construction -- under the same counters in the same gpurun call (the raw figure read 1.17 at
+saturation); useful_lane_frac = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU): the share of issued vector lane-slots that worked."""
 import collections, csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,10 +17,13 @@ path, sq_dir, stats = sys.argv[1:4]
 d = json.load(open(path))
 acc = collections.defaultdict(list)
 gui = collections.defaultdict(list)
+thr = collections.defaultdict(list)
 for f in glob.glob(os.path.join(sq_dir, '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == 'SQ_ACTIVE_INST_VALU' and 'gendr' in r['Kernel_Name']:
             acc[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
+        if r['Counter_Name'] == 'SQ_THREAD_CYCLES_VALU' and 'gendr' in r['Kernel_Name']:
+            thr[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
         if r['Counter_Name'] == 'GRBM_GUI_ACTIVE' and 'gendr' in r['Kernel_Name']:
             gui[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
 quad = {}
@@ -62,7 +68,38 @@ d['valu_busy_note'] = ('valu_busy = SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs
                        'valu_busy_by_gpu_cycles = the same over GRBM_GUI_ACTIVE / 8 XCDs of the same launch (no clock assumption, but the '
                        'counter spans the whole dispatch); the counter pass runs tools/kbench.py at the batch recorded in sq_batch, the traffic '
                        'passes run bench.py at the batch recorded in traffic_batch')
+lanes = {}
+for k, v in thr.items():
+    g = max(x[0] for x in v)
+    vals = [x[1] for x in v if x[0] == g]
+    if quad.get(k):
+        lanes[k] = (sum(vals) / len(vals)) / (64.0 * quad[k])
+d['useful_lane_frac'] = lanes
 if len(sys.argv) > 4:
     d['sq_batch'] = int(sys.argv[4])
+# calibration pass (tools/micro/valucal.hip under the same counters): what the occupation expression reads at 100 %
+if len(sys.argv) > 5:
+    cq, cg, ct, cd = [], [], [], []
+    for f in glob.glob(os.path.join(sys.argv[5], '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'valu_calibration_kernel' not in r['Kernel_Name']:
+                continue
+            {'SQ_ACTIVE_INST_VALU': cq, 'GRBM_GUI_ACTIVE': cg, 'SQ_THREAD_CYCLES_VALU': ct}.get(r['Counter_Name'], []).append(float(r['Counter_Value']))
+    for f in glob.glob(os.path.join(sys.argv[5], '**', '*kernel_trace.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'valu_calibration_kernel' in r['Kernel_Name']:
+                cd.append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-3)
+    if cq and cd:
+        med = lambda v: sorted(v)[len(v) // 2]
+        f_nom = med(cq) * 4 / (1024 * med(cd) * 1e-6 * 2.4e9)
+        f_gui = med(cq) * 4 / (1024 * med(cg) / 8.0) if cg else None
+        d['valu_calibration'] = {'kernel': 'tools/micro/valucal.hip (8 waves per SIMD of independent v_fma_f32: occupation 1.00 by construction)',
+                                 'reads_by_nominal_clock': f_nom, 'reads_by_gpu_cycles': f_gui,
+                                 'lane_frac_reads': (med(ct) / (64.0 * med(cq))) if ct else None, 'duration_us': med(cd)}
+        d['valu_busy_calibrated'] = {k: v / f_nom for k, v in d['valu_busy'].items()}
+        if f_gui:
+            d['valu_busy_by_gpu_cycles_calibrated'] = {k: v / f_gui for k, v in d['valu_busy_by_gpu_cycles'].items()}
+        d['valu_busy_note'] += ('; *_calibrated = divided by what the same expression reads for the calibration kernel in the same gpurun call '
+                                '(valu_calibration)')
 json.dump(d, open(path, 'w'), indent=1)
 print(json.dumps({k: round(v, 3) for k, v in d['valu_busy'].items()}), d['kernel_sha'])
