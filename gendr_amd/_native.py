@@ -191,3 +191,38 @@ def lib(variant=None):
 
 def error_string(code):
     return lib().gendr_error_string(int(code)).decode()
+
+
+# ---- the C++ autograd node (gendr_amd/csrc/gendr_torch.cpp -> _gendr_torch.so) -------------------------------------------------------
+TORCH_EXT_PATH = os.path.join(_HERE, "_gendr_torch.so")
+_torch_ext = None
+_torch_slots = {}
+
+
+def torch_ext():
+    """The compiled autograd node, or None when it is not built (the ctypes-based GenDRFunction then does the same work: both paths
+    end in the same two C-ABI calls, neither is a fallback off the HIP kernels)."""
+    global _torch_ext
+    if _torch_ext is None:
+        if not os.path.exists(TORCH_EXT_PATH):
+            _torch_ext = False
+        else:
+            import importlib.util
+            import torch  # noqa: F401  (its libraries must be loaded first)
+            spec = importlib.util.spec_from_file_location("_gendr_torch", TORCH_EXT_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            _torch_ext = mod
+    return _torch_ext or None
+
+
+def torch_slot(variant=None):
+    """Slot of the active library variant's entry points inside the C++ node (bound once per variant)."""
+    variant = variant or _active
+    if variant not in _torch_slots:
+        L = lib(variant)
+        addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value
+        _torch_slots[variant] = torch_ext().bind(addr(L.gendr_validate), addr(L.gendr_workspace_bytes), addr(L.gendr_forward),
+                                                 addr(L.gendr_backward), addr(L.gendr_error_string), L.gendr_params_size(),
+                                                 L.gendr_abi_version())
+    return _torch_slots[variant]

@@ -79,6 +79,55 @@ def build(force=False, verbose=False, variant="default"):
     return path
 
 
+# ---- the C++ autograd node (csrc/gendr_torch.cpp): host-side plumbing over the C ABI, compiled with g++ against the installed PyTorch
+TORCH_EXT_SRC = os.path.join(CSRC, "gendr_torch.cpp")
+TORCH_EXT_PATH = os.path.join(_HERE, "_gendr_torch.so")
+
+
+def torch_ext_needs_build():
+    if not os.path.exists(TORCH_EXT_PATH):
+        return True
+    built = os.path.getmtime(TORCH_EXT_PATH)
+    return any(os.path.getmtime(d) > built for d in (TORCH_EXT_SRC, os.path.join(CSRC, "..", "..", "include", "gendr_hip.h")))
+
+
+def build_torch_ext(force=False, verbose=False):
+    """gendr_amd/_gendr_torch.so: GenDRFunction as a torch::autograd::Function (two native calls per step, no Python frames).  Plain
+    g++ -- the file holds no device code and uses PyTorch-ROCm's own c10::hip names, nothing is hipified; it binds the C-ABI entry
+    points of libgendr_hip*.so at run time (addresses handed over by gendr_amd/_native.py), so it links none of them."""
+    if not (force or torch_ext_needs_build()):
+        return TORCH_EXT_PATH
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    import pybind11
+    import fcntl
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cxx = shutil.which("g++") or "g++"
+    with open(TORCH_EXT_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or torch_ext_needs_build():
+                tmp = "%s.%d.tmp" % (TORCH_EXT_PATH, os.getpid())
+                cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+                       "-DTORCH_EXTENSION_NAME=_gendr_torch", "-DTORCH_API_INCLUDE_EXTENSION_H",
+                       "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+                cmd += ["-I" + d for d in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(), "-I/opt/rocm/include"]
+                cmd += [TORCH_EXT_SRC, "-o", tmp, "-L" + tl, "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python",
+                        "-Wl,-rpath," + tl]
+                if verbose:
+                    print(" ".join(cmd))
+                try:
+                    subprocess.check_call(cmd)
+                    os.replace(tmp, TORCH_EXT_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return TORCH_EXT_PATH
+
+
 def source_sha():
     """Short hash of the kernel sources: stamps the profiler summaries under profiles/ so that bench.py only quotes
     counters that were collected on THESE kernels."""
@@ -107,3 +156,4 @@ if __name__ == "__main__":
     import sys
     names = tuple(a for a in sys.argv[1:] if a in VARIANTS) or DEFAULT_VARIANTS
     print(build_all(force="--force" in sys.argv or len(sys.argv) == 1, verbose=True, variants=names))
+    print(build_torch_ext(force="--force" in sys.argv, verbose=True))

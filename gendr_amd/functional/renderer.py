@@ -114,6 +114,33 @@ def make_params(image_size, background_color, dist_func, dist_scale, dist_square
     return p
 
 
+_CPP_AUTOGRAD = os.environ.get('GENDR_CPP_AUTOGRAD', '1') != '0'
+_PARAMS_CACHE = {}
+_ENV_KEYS = ('GENDR_TEXEL_MODE', 'GENDR_CULL', 'GENDR_DETERMINISTIC', 'GENDR_POOL_ENTRIES_MAX', 'GENDR_PAIR_HINTS', 'GENDR_LOOSE_FACES',
+             'GENDR_SKIP_UNLISTED_AUX', 'GENDR_FUSED_CLEAR')
+
+
+def _params_bytes(image_size, background_color, *options):
+    """(gendr_params as bytes, fused gradient clear?) for the C++ node; cached per option set and environment -- an optimisation loop
+    renders with the same options thousands of times, and normalising them costs the host more than the launch."""
+    env = tuple(os.environ.get(k) for k in _ENV_KEYS)
+    try:
+        key = (image_size, tuple(background_color), options, env)
+        hit = _PARAMS_CACHE.get(key)
+    except TypeError:                                   # an unhashable option (a tensor-valued scalar, ...): no caching
+        key, hit = None, None
+    if hit is None:
+        p = make_params(image_size, background_color, *options)
+        # aggrs_info stays inside the node (saved for backward, which never looks at tiles no face reaches)
+        p.skip_unlisted_aux = 1 if os.environ.get('GENDR_SKIP_UNLISTED_AUX', '1') != '0' else 0
+        hit = (bytes(p), os.environ.get('GENDR_FUSED_CLEAR', '1') != '0')
+        if key is not None:
+            if len(_PARAMS_CACHE) > 256:
+                _PARAMS_CACHE.clear()
+            _PARAMS_CACHE[key] = hit
+    return hit
+
+
 def check(code, what):
     if code != 0:
         msg = '%s: %s (code %d)' % (what, _native.error_string(code), code)
@@ -342,7 +369,20 @@ def render(
     double_side=True,
     texture_type='surface',
 ):
-    """``gendr.functional.render`` (``functional/renderer.py:239-288``)."""
+    """``gendr.functional.render`` (``functional/renderer.py:239-288``).
+
+    float32 CUDA inputs go through the C++ autograd node (``csrc/gendr_torch.cpp``: the same host logic as ``GenDRFunction``
+    without the Python frames -- one C++ call per pass, like the reference's pybind launcher ``generalized_renderer_cuda.cpp:74-192``);
+    everything else (float64, ``GENDR_CPP_AUTOGRAD=0``, event-sampled steps of bench.py, an unbuilt extension) through
+    ``GenDRFunction``.  Both end in the same two C-ABI calls of libgendr_hip.so."""
+    if PROFILE_EVENTS is None and face_vertices.dtype == torch.float32 and textures.dtype == torch.float32 and face_vertices.is_cuda \
+            and textures.is_cuda and _CPP_AUTOGRAD:
+        ext = _native.torch_ext()
+        if ext is not None:
+            pb, fused = _params_bytes(image_size, background_color, dist_func, dist_scale, dist_squared, dist_shape, dist_shift, dist_eps,
+                                      aggr_alpha_func, aggr_alpha_t_conorm_p, aggr_rgb_func, aggr_rgb_eps, aggr_rgb_gamma, near, far,
+                                      double_side, texture_type)
+            return ext.render(face_vertices, textures, pb, _native.torch_slot(), fused)
     return GenDRFunction.apply(
         face_vertices, textures, image_size, background_color,
         dist_func, dist_scale, dist_squared, dist_shape, dist_shift, dist_eps,

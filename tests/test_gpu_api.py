@@ -267,3 +267,42 @@ def test_clear_ptr_of_the_c_abi(native_lib):
     p.clear_ptr = buf.data_ptr() + 4                       # not 16-byte aligned
     with pytest.raises(Exception):
         R.native_forward(faces, textures, p)
+
+
+def test_cpp_autograd_node_equals_the_python_function(native_lib):
+    """`render()` takes float32 CUDA inputs through the C++ autograd node (csrc/gendr_torch.cpp: the same host logic as
+    GenDRFunction, two C-ABI calls per step, no Python frames); switched off it goes through GenDRFunction.  Same images bit
+    for bit, same gradients up to the atomics' order, the same exception types, graph-capturable, retain_graph works."""
+    from gendr_amd import _native
+    from gendr_amd.functional import renderer as R
+    assert _native.torch_ext() is not None, 'gendr_amd/_gendr_torch.so is not built (gendr_amd.build.build_torch_ext())'
+    fv, tex = _inputs(B=3, nf=40)
+    g = None
+    out = {}
+    for mode in (True, False):
+        R._CPP_AUTOGRAD = mode
+        try:
+            a, t = fv.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+            img = R.render(a, t, image_size=48, dist_func='logistic', dist_scale=2e-2, background_color=[0.1, 0.2, 0.3])
+            assert ('GenDRFunction' in img.grad_fn.name()) == (not mode), img.grad_fn.name()
+            g = torch.randn_like(img) if g is None else g
+            img.backward(g, retain_graph=True)
+            first = a.grad.clone()
+            a.grad = None; t.grad = None
+            img.backward(g)                                   # a second backward through the same graph: its own, filled buffers
+            assert torch.allclose(a.grad, first, rtol=1e-4, atol=1e-6)
+            out[mode] = (img.detach(), a.grad.clone(), t.grad.clone())
+        finally:
+            R._CPP_AUTOGRAD = True
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.allclose(out[True][1], out[False][1], rtol=1e-4, atol=1e-6) and torch.allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-6)
+    with pytest.raises(ValueError):
+        R.render(fv, tex, image_size=32, dist_func=23)
+    with pytest.raises(ValueError):
+        R.render(fv, tex[:, :5], image_size=32)
+    with pytest.raises(TypeError):
+        R.render(fv.cpu(), tex, image_size=32)
+    # no differentiable input, inference mode, [B, nf, 9] faces
+    with torch.no_grad():
+        b = R.render(fv.reshape(3, 40, 9), tex, image_size=48, dist_func='logistic', dist_scale=2e-2, background_color=[0.1, 0.2, 0.3])
+    assert torch.equal(b, out[True][0])

@@ -128,3 +128,20 @@ def test_null_pointers_are_rejected_not_dereferenced(native_lib):
     p = _params()
     assert native_lib.gendr_forward(None, None, None, None, None, 1, 1, 1, ctypes.byref(p), None) == -1
     assert native_lib.gendr_face_info(None, None, 1, 1, None) == -1
+
+
+def test_cpp_autograd_node_builds_and_binds(native_lib):
+    """gendr_amd/_gendr_torch.so (csrc/gendr_torch.cpp): loads without a GPU, takes the C-ABI entry points of the loaded library by
+    address (it links none of them), refuses another ABI, and raises the reference-shaped TypeError for CPU tensors."""
+    import ctypes
+    import torch
+    from gendr_amd import build, _native
+    build.build_torch_ext()
+    ext = _native.torch_ext()
+    assert ext is not None and hasattr(ext, 'bind') and hasattr(ext, 'render')
+    slot = _native.torch_slot()
+    assert slot == _native.torch_slot()                       # bound once per variant
+    with pytest.raises(RuntimeError):
+        ext.bind(0, 0, 0, 0, 0, native_lib.gendr_params_size(), native_lib.gendr_abi_version() + 1)
+    with pytest.raises(TypeError):
+        ext.render(torch.zeros(1, 2, 3, 3), torch.zeros(1, 2, 1, 3), bytes(ctypes.sizeof(_native.GendrParams)), slot, True)
