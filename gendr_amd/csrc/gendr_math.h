@@ -94,6 +94,28 @@ GENDR_HD float div_by(float a, rcp_t rb)
 #endif
 }
 
+// RN_double(n / b) for doubles, given rb = RN_double(1 / b) -- the CORRECTLY ROUNDED reciprocal (the host's division) -- without a
+// division: q = n rb is within two ulps of the quotient; one residual correction (r = n - q b is exact in an fma) makes it
+// faithful, and by Markstein's theorem a second one with a correctly rounded reciprocal yields the correctly rounded quotient
+// (the `provably exact five-instruction form` of DESIGN 3.6, in double; 4e8 random operand pairs against the IEEE division on
+// the host: tools/div5_check.c).  Five full-rate-f64 operations against the ~15 of the compiler's IEEE f64 division expansion
+// (v_div_scale x2, v_rcp_f64, v_div_fmas, v_div_fixup and the Newton steps): the uniform and cubic CDFs' `x * 0.5 / scale`
+// (kernel.cu:274, :283) is a double division by a call-wide constant in every pair of BASELINE config 2.  Operands here are
+// finite and normal (the branch is taken for |u| < 1 only); host: the division itself.
+GENDR_HD double div_rn_f64(double n, double b, double rb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double q = n * rb;
+    double r = __builtin_fma(-q, b, n);
+    q = __builtin_fma(r, rb, q);
+    r = __builtin_fma(-q, b, n);
+    return __builtin_fma(r, rb, q);
+#else
+    (void)rb;
+    return n / b;
+#endif
+}
+
 // Reciprocal of a positive, finite, normal double for use with div_by(): the argument above leaves 2^-49 - 2^-52 of
 // slack, so rb may be off by a few ulps.  On the device: v_rcp_f64 and two Newton steps (error < 2 ulp, 5
 // instructions) instead of the IEEE f64 division expansion (~15); on the host the true quotient.
@@ -329,7 +351,7 @@ template <> struct Dist<kUniform> {
 #if GENDR_FAST_DEV
         if (u < 1) return __builtin_fmaf(0.5f, u, 0.5f);
 #else
-        if (u < 1) return (float)((double)(sign * x) * 0.5 / (double)d.scale + 0.5);
+        if (u < 1) return (float)(div_rn_f64((double)(sign * x) * 0.5, (double)d.scale, d.rscale) + 0.5);
 #endif
         return 1.f;
     }
@@ -344,7 +366,11 @@ template <> struct Dist<kCubicHermite> {
         const float u = div_by(sign * x, d.rscale);
         if (u < -1) return 0.f;
         if (u < 1) {
+#if GENDR_FAST_DEV
             const float y = (float)((double)(sign * x) * 0.5 / (double)d.scale + 0.5);
+#else
+            const float y = (float)(div_rn_f64((double)(sign * x) * 0.5, (double)d.scale, d.rscale) + 0.5);
+#endif
             return 3 * y * y - 2 * y * y * y;
         }
         return 1.f;

@@ -59,6 +59,9 @@ def _check_equal_blocks(n_local, group):
     block size let a ragged step send one rank into the all-gather while another issued this all-reduce -- mismatched
     collectives, i.e. the hang the check exists to prevent).  Callers that shard evenly pass
     ``assume_equal_blocks=True`` and skip it."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('gather_views: the equal-block check reads a value back on the host and cannot run inside a HIP graph capture; '
+                           'callers that shard evenly pass assume_equal_blocks=True (bench.py does)')
     t = torch.tensor([n_local, -n_local], dtype=torch.int64)
     if dist.get_backend(group) != 'gloo':
         t = t.cuda()
@@ -106,7 +109,8 @@ def gather_views(images, group=None, assume_equal_blocks=False):
     """[B_local, ...] on every rank -> [world * B_local, ...] on every rank, differentiable.
     A no-op without an initialised process group (single GPU).  Every rank must hand over the same number of
     views; that is verified with one small all-reduce per call unless ``assume_equal_blocks`` (callers that
-    sharded with an even ``shard_range`` already know)."""
+    sharded with an even ``shard_range`` already know).  The check reads the result back on the host: a step that is to be
+    captured in a HIP graph has to pass ``assume_equal_blocks=True`` (the check raises inside a capture instead of breaking it)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return images
     return _GatherViews.apply(images, group, assume_equal_blocks)

@@ -81,6 +81,21 @@ def reference_available(name='render'):
     return ref_gpu.available(name)
 
 
+def require_reference(*names):
+    """For fixtures of the reference-pin tests: oracle/_ref travels to the GPU box prebuilt, /root/reference does not exist there.
+    Where the reference's sources ARE present (the build container) a missing oracle/_ref means oracle/build_ref.py failed --
+    that must be a red result, not a silent skip of the only gate against the reference's own kernels."""
+    import os
+    import pytest
+    missing = [n for n in (names or ('render',)) if not reference_available(n)]
+    if not missing:
+        return
+    msg = 'oracle/_ref is not built (%s; python -m oracle.build_ref needs /root/reference)' % ', '.join(missing)
+    if os.path.isdir('/root/reference') and os.environ.get('GENDR_ALLOW_MISSING_REF') != '1':
+        pytest.fail(msg + ' -- the reference IS present here, so the build failed: fix it (GENDR_ALLOW_MISSING_REF=1 skips instead)')
+    pytest.skip(msg)
+
+
 def run_reference(fv, tex, image_size, opts, grad=None, dtype=np.float32, variant='render'):
     """The REFERENCE's own kernels on the GPU (oracle/_ref, built by oracle/build_ref.py from the reference's .cu file;
     launched by oracle/ref_gpu.py).  Same inputs / outputs as run_oracle.  texel_mode has no meaning here (the reference

@@ -40,8 +40,7 @@ ISZ = 64
 
 @pytest.fixture(scope='module')
 def ref_kernels():
-    if not parity.reference_available():
-        pytest.skip('oracle/_ref is not built (python -m oracle.build_ref needs /root/reference)')
+    parity.require_reference()
 
 
 def _scene(B):

@@ -69,8 +69,7 @@ EPS_REGIMES = (1.0, 1.5, 3.0, 10.0, 30.0, 100.0, 300.0)
 
 @pytest.fixture(scope='module')
 def ref_builds():
-    if not (parity.reference_available() and parity.reference_available('render_fma')):
-        pytest.skip('oracle/_ref (both builds of the reference\'s kernels) is not built')
+    parity.require_reference('render', 'render_fma')
 
 
 def _agreeing(r1, r2, key, scale=None):

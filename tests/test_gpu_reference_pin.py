@@ -28,8 +28,7 @@ IDS = [n for n, _ in MATRIX]
 
 @pytest.fixture(scope='module')
 def ref_kernels():
-    if not parity.reference_available():
-        pytest.skip('oracle/_ref is not built (python -m oracle.build_ref needs /root/reference)')
+    parity.require_reference()
 
 
 def _inputs(opts, scene):

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _need(name):
-    if not ref_gpu.available(name):
-        pytest.skip('oracle/_ref/%s is not built (python -m oracle.build_ref needs /root/reference)' % name)
+    import parity
+    parity.require_reference(name)
 
 
 SCENES = {'spheres': lambda: sphere_faces(3, 2), 'box': box_faces, 'shells': nested_shells, 'soup': soup}
