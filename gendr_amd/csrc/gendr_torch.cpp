@@ -30,6 +30,8 @@ typedef const char* (*errstr_fn)(int);
 
 struct Api { validate_fn validate; ws_bytes_fn ws_bytes; forward_fn forward; backward_fn backward; errstr_fn errstr; };
 std::vector<Api> g_api;      // one per bound library variant (gendr_amd/_native.py: default, exact, ...)
+// what the last calls did (tests/test_gpu_api.py: a differentiated step must run with pair hints and reuse the cleared buffer)
+int64_t g_forward_with_grad = 0, g_forward_with_hints_off = 0, g_backward_prefilled = 0, g_backward_filled_here = 0;
 
 void check(const Api& api, int code, const char* what)
 {
@@ -41,7 +43,7 @@ void check(const Api& api, int code, const char* what)
 
 struct GenDRNode : public torch::autograd::Function<GenDRNode> {
     static torch::Tensor forward(torch::autograd::AutogradContext* ctx, const torch::Tensor& face_vertices, const torch::Tensor& textures,
-                                 const std::string& params_bytes, int64_t api_slot, bool fused_clear)
+                                 const std::string& params_bytes, int64_t api_slot, bool fused_clear, bool want_grad)
     {
         const Api& api = g_api.at((size_t)api_slot);
         gendr_params p;
@@ -57,10 +59,13 @@ struct GenDRNode : public torch::autograd::Function<GenDRNode> {
             throw py::value_error("textures must be [B, nf, T, 3] matching face_vertices [B, nf, 3, 3]");
         const int64_t T = tex.size(2);
         check(api, api.validate(&p, (int)B, (int)nf, (int)T), "gendr.render");
-        // (not ctx->needs_input_grad(): without a differentiable input the C++ node has no edges to ask)
-        const bool want_grad = at::GradMode::is_enabled() && (face_vertices.requires_grad() || textures.requires_grad());
+        // (`want_grad` comes from render(): inside a custom Function's forward the grad mode is already switched off, and without a
+        // differentiable input the node has no edges for ctx->needs_input_grad() to ask -- a first version asked GradMode here, got
+        // "off" every time, and ran every step without pair hints and without the fused gradient clear: backward 100 instead of 88 us)
         // pair hints (ABI 6) are for the backward call: a forward pass nobody differentiates does not pay for them
         if (!want_grad && p.pair_hints == 0) p.pair_hints = -1;
+        g_forward_with_grad += want_grad;
+        g_forward_with_hints_off += p.pair_hints < 0;
         const auto opts = faces.options();
         const int64_t isz = p.image_size;
         torch::Tensor rgba = torch::empty({B, 4, isz, isz}, opts), aux = torch::empty({B, 2, isz, isz}, opts);
@@ -109,9 +114,11 @@ struct GenDRNode : public torch::autograd::Function<GenDRNode> {
         auto it = ctx->saved_data.find("flat");
         if (it != ctx->saved_data.end() && it->second.isTensor()) {
             flat = it->second.toTensor();
+            g_backward_prefilled++;
             ctx->saved_data.erase("flat");               // cleared by the forward call: good for one use (retain_graph: a fresh, filled one)
         } else {
             flat = torch::zeros({(n_f_pad + n_t + 3) / 4 * 4}, faces.options());
+            g_backward_filled_here++;
         }
         torch::Tensor grad_faces = flat.narrow(0, 0, n_f).view({B, nf, 9});
         torch::Tensor grad_tex = flat.narrow(0, n_f_pad, n_t).view(tex.sizes());
@@ -125,7 +132,7 @@ struct GenDRNode : public torch::autograd::Function<GenDRNode> {
         const auto fv_sizes = ctx->saved_data["fv_sizes"].toIntVector();
         torch::Tensor gf = grad_faces.reshape(fv_sizes).to((c10::ScalarType)ctx->saved_data["fv_dtype"].toInt());
         torch::Tensor gt = grad_tex.to((c10::ScalarType)ctx->saved_data["tex_dtype"].toInt());
-        return {gf, gt, torch::Tensor(), torch::Tensor(), torch::Tensor()};
+        return {gf, gt, torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
     }
 };
 
@@ -138,7 +145,8 @@ int64_t bind(int64_t validate, int64_t ws_bytes, int64_t forward, int64_t backwa
 
 torch::Tensor render(const torch::Tensor& face_vertices, const torch::Tensor& textures, const py::bytes& params, int64_t api_slot, bool fused_clear)
 {
-    return GenDRNode::apply(face_vertices, textures, std::string(params), api_slot, fused_clear);
+    const bool want_grad = at::GradMode::is_enabled() && (face_vertices.requires_grad() || textures.requires_grad());
+    return GenDRNode::apply(face_vertices, textures, std::string(params), api_slot, fused_clear, want_grad);
 }
 
 }  // namespace
@@ -146,5 +154,8 @@ torch::Tensor render(const torch::Tensor& face_vertices, const torch::Tensor& te
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("bind", &bind, "registers the C-ABI entry points of one loaded libgendr_hip*.so; returns its slot");
+    m.def("stats", []() { return py::dict(py::arg("forward_with_grad") = g_forward_with_grad, py::arg("forward_with_hints_off") = g_forward_with_hints_off,
+                                          py::arg("backward_prefilled") = g_backward_prefilled, py::arg("backward_filled_here") = g_backward_filled_here); },
+          "counters of what the node's calls did so far");
     m.def("render", &render, "GenDRFunction as a C++ autograd node: (face_vertices, textures, gendr_params bytes, api slot, fused clear) -> rgba");
 }

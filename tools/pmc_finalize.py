@@ -18,10 +18,13 @@ d = json.load(open(path))
 acc = collections.defaultdict(list)
 gui = collections.defaultdict(list)
 thr = collections.defaultdict(list)
+busy = collections.defaultdict(list)
 for f in glob.glob(os.path.join(sq_dir, '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == 'SQ_ACTIVE_INST_VALU' and 'gendr' in r['Kernel_Name']:
             acc[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
+        if r['Counter_Name'] == 'SQ_BUSY_CYCLES' and 'gendr' in r['Kernel_Name']:
+            busy[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
         if r['Counter_Name'] == 'SQ_THREAD_CYCLES_VALU' and 'gendr' in r['Kernel_Name']:
             thr[short(r['Kernel_Name'])].append((int(r.get('Grid_Size', 0) or 0), float(r['Counter_Value'])))
         if r['Counter_Name'] == 'GRBM_GUI_ACTIVE' and 'gendr' in r['Kernel_Name']:
@@ -79,12 +82,12 @@ if len(sys.argv) > 4:
     d['sq_batch'] = int(sys.argv[4])
 # calibration pass (tools/micro/valucal.hip under the same counters): what the occupation expression reads at 100 %
 if len(sys.argv) > 5:
-    cq, cg, ct, cd = [], [], [], []
+    cq, cg, ct, cd, cb = [], [], [], [], []
     for f in glob.glob(os.path.join(sys.argv[5], '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if 'valu_calibration_kernel' not in r['Kernel_Name']:
                 continue
-            {'SQ_ACTIVE_INST_VALU': cq, 'GRBM_GUI_ACTIVE': cg, 'SQ_THREAD_CYCLES_VALU': ct}.get(r['Counter_Name'], []).append(float(r['Counter_Value']))
+            {'SQ_ACTIVE_INST_VALU': cq, 'GRBM_GUI_ACTIVE': cg, 'SQ_THREAD_CYCLES_VALU': ct, 'SQ_BUSY_CYCLES': cb}.get(r['Counter_Name'], []).append(float(r['Counter_Value']))
     for f in glob.glob(os.path.join(sys.argv[5], '**', '*kernel_trace.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if 'valu_calibration_kernel' in r['Kernel_Name']:
@@ -96,10 +99,24 @@ if len(sys.argv) > 5:
         d['valu_calibration'] = {'kernel': 'tools/micro/valucal.hip (8 waves per SIMD of independent v_fma_f32: occupation 1.00 by construction)',
                                  'reads_by_nominal_clock': f_nom, 'reads_by_gpu_cycles': f_gui,
                                  'lane_frac_reads': (med(ct) / (64.0 * med(cq))) if ct else None, 'duration_us': med(cd)}
-        d['valu_busy_calibrated'] = {k: v / f_nom for k, v in d['valu_busy'].items()}
-        if f_gui:
-            d['valu_busy_by_gpu_cycles_calibrated'] = {k: v / f_gui for k, v in d['valu_busy_by_gpu_cycles'].items()}
-        d['valu_busy_note'] += ('; *_calibrated = divided by what the same expression reads for the calibration kernel in the same gpurun call '
-                                '(valu_calibration)')
+        d['valu_calibration']['effective_clock_ghz_of_the_calibration_pass'] = 2.4 * f_nom
+        # The occupation as a FRACTION: vector-instruction quad-cycles over the SQ's busy quad-cycles of the SAME
+        # dispatch -- both in the shader-clock domain, so the clock of the pass (1.9 GHz for the calibration kernel under counters, up
+        # to 2.4 GHz for sparser kernels: MI355X_MICROARCH.md) drops out -- normalised by the same ratio of the calibration kernel,
+        # whose vector pipes are occupied 100 % by construction (that fixes the counters' aggregation over XCDs / SEs).
+        if cb:
+            r_cal = med(cq) / med(cb)
+            d['valu_calibration']['active_over_busy_reads'] = r_cal
+            vb = {}
+            for k, v in busy.items():
+                g = max(x[0] for x in v)
+                vals = [x[1] for x in v if x[0] == g]
+                if quad.get(k) and vals:
+                    vb[k] = (quad[k] / (sum(vals) / len(vals))) / r_cal
+            d['valu_busy_calibrated'] = vb
+        d['valu_busy_note'] += ('; valu_busy_calibrated = (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the same dispatch) / (the same ratio of '
+                                'tools/micro/valucal.hip, occupied 100 %% by construction, collected in the same gpurun call): a fraction, '
+                                'independent of the clock the pass ran at -- the raw valu_busy assumes 2.4 GHz, and the calibration kernel '
+                                'itself reads %.2f by that assumption because profiled dense-VALU passes clock at %.2f GHz' % (f_nom, 2.4 * f_nom))
 json.dump(d, open(path, 'w'), indent=1)
 print(json.dumps({k: round(v, 3) for k, v in d['valu_busy'].items()}), d['kernel_sha'])
