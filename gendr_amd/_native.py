@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgendr_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GendrParams(ctypes.Structure):
@@ -44,6 +44,7 @@ class GendrParams(ctypes.Structure):
         ("pool_entries_max", ctypes.c_ulonglong),
         ("pair_hints", ctypes.c_int),
         ("loose_faces", ctypes.c_int),
+        ("team", ctypes.c_int),
     ]
 
 
@@ -69,6 +70,7 @@ EXPORTS = (
     "gendr_cull_radius", "gendr_project_faces", "gendr_project_faces_backward",
     "gendr_camera_rotation", "gendr_camera_rotation_backward",
     "gendr_silhouette_workspace_bytes", "gendr_silhouette_forward", "gendr_silhouette_backward", "gendr_workspace_bytes_f64", "gendr_forward_f64", "gendr_backward_f64", "gendr_selftest", "gendr_light_faces", "gendr_light_faces_backward", "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
+    "gendr_uses_team",
 )
 
 _libs = {}
@@ -175,6 +177,8 @@ def lib(variant=None):
     L.gendr_project_faces.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, vp]
     L.gendr_project_faces_backward.restype = i
     L.gendr_project_faces_backward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
+    L.gendr_uses_team.restype = i
+    L.gendr_uses_team.argtypes = [i, i, i, pp, i]
     L.gendr_cull_radius.restype = f
     L.gendr_cull_radius.argtypes = [pp]
     L.gendr_params_size.restype = i

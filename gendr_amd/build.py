@@ -31,7 +31,7 @@ def lib_path(variant="default"):
         raise ValueError("unknown build variant %r (have %s)" % (variant, sorted(VARIANTS)))
     return LIB_PATH if variant == "default" else os.path.join(_HERE, "libgendr_hip_%s.so" % variant)
 SOURCES = ["gendr_capi.hip"]
-HEADERS = ["gendr_kernels.h", "gendr_math.h", "gendr_project.h", "gendr_voxel.h", "gendr_texture.h", "gendr_light.h", os.path.join("compat", "gendr_f64.h"), os.path.join("..", "..", "include", "gendr_hip.h")]
+HEADERS = ["gendr_kernels.h", "gendr_team.h", "gendr_math.h", "gendr_project.h", "gendr_voxel.h", "gendr_texture.h", "gendr_light.h", os.path.join("compat", "gendr_f64.h"), os.path.join("..", "..", "include", "gendr_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-munsafe-fp-atomics", "-fno-slp-vectorize"]
 

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "gendr_kernels.h"
+#include "gendr_team.h"
 #include "gendr_project.h"
 #include "gendr_voxel.h"
 #include "gendr_texture.h"
@@ -59,6 +60,18 @@ struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; faces_kernel_t det
 #ifndef C5B
 #define C5B wa
 #endif
+// -DGENDR_DEV_MIN=1 (tools/devbuild.sh): a library with the kernels of ONE regime only -- opt_shape.py's two renderers and the team
+// kernels -- that compiles in seconds instead of minutes, for A/B experiments on those kernels.  Never shipped: every other option
+// set lands on a kernel of another option set.
+#ifndef GENDR_DEV_MIN
+#define GENDR_DEV_MIN 0
+#endif
+#if GENDR_DEV_MIN
+const KernelEntry kSpecialised[] = {
+    GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 0, 0, kTexSurface1),
+    GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),
+};
+#else
 const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_K(kUniform,     kProbabilistic, 1, 0, kTexSurface1, w6, C2B),  // C2 headline; library defaults
     GENDR_SPECIALISE_K(kGaussian,    kEinstein,      1, 1, kTexSurface1, w6, wa),   // C3 (backward: 4 waves, less spill)
@@ -72,7 +85,22 @@ const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_K(kLogistic,    kProbabilistic, kRgbNone, 0, kTexSurfaceN, w6, wa),
     GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     kRgbNone, 0, kTexSurfaceN),
 };
+#endif
 
+// Team kernels (gendr_team.h; gendr_params::team): one workgroup per tile, for calls of few tiles with thousands of pairs each.
+// The option sets whose one-wave kernels have the dense path and that the reference's scripts put into that regime.
+struct TeamEntry { KernelKey key; render_kernel_t fwd, bwd; };
+#define GENDR_TEAM_ROW(D, A, RGB, SQ, TEXM) \
+    { {D, A, RGB, SQ, TEXM}, render_forward_team_kernel<D, A, RGB, SQ, TEXM>, render_backward_team_kernel<D, A, RGB, SQ, TEXM> }
+const TeamEntry kTeam[] = {
+    GENDR_TEAM_ROW(kLogistic, kProbabilistic, 0, 0, kTexSurface1),          // opt_shape.py:134-145 soft renderer
+#if !GENDR_DEV_MIN
+    GENDR_TEAM_ROW(kLogistic, kProbabilistic, 1, 0, kTexSurface1),          // BASELINE config 4's option set at small batches
+    GENDR_TEAM_ROW(kLogistic, kProbabilistic, kRgbNone, 0, kTexSurfaceN),   // the alpha-only twin
+#endif
+};
+
+#if !GENDR_DEV_MIN
 // alpha-only runtime-dispatch kernels, by the same four classes as kGeneric
 #define GENDR_SIL_ROW(D, A, K) \
     { {D, A, kRgbNone, -1, kTexSurfaceN}, render_forward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN>, render_backward_kernel_##K<D, A, kRgbNone, -1, kTexSurfaceN>, \
@@ -98,6 +126,7 @@ const KernelEntry kGeneric[2][2][3] = {
     { GENDR_GENERIC_CLASS(-1, -1, wf), GENDR_GENERIC_CLASS(-1, -2, wf) },
     { GENDR_GENERIC_CLASS(-2, -1, wa), GENDR_GENERIC_CLASS(-2, -2, wl) },
 };
+#endif
 
 const KernelEntry& pick_generic(const gendr_params* p, int texm, bool silhouette);
 
@@ -118,13 +147,37 @@ const KernelEntry& pick_kernel(const gendr_params* p, int texm, bool silhouette 
 // the runtime-dispatch row of an option set (also the home of the deterministic backward kernels)
 const KernelEntry& pick_generic(const gendr_params* p, int texm, bool silhouette)
 {
+#if GENDR_DEV_MIN
+    return kSpecialised[0];
+#else
     if (silhouette) return kGenericSil[is_light_dist(p->dist_func) ? 1 : 0][is_light_alpha(p->aggr_alpha_func) ? 1 : 0];
     return kGeneric[is_light_dist(p->dist_func) ? 1 : 0][is_light_alpha(p->aggr_alpha_func) ? 1 : 0][texm];
+#endif
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" float gendr_cull_radius(const gendr_params* p);
+
+// gendr_params::team.  Automatic: the call holds at most kTeamMaxTiles tiles and the cull radius is at least kTeamMinRadiusPx
+// pixels -- few tiles, each listing a face for every pixel within that radius (opt_shape.py: 1 536 tiles, 4.4 pixels, 4 000 pairs per
+// live tile: forward 169 -> us, backward 170 -> us per call); with many tiles or short tails one wave per tile is the
+// better shape.  Needs the entry pool (the team walks coverage entries) and the exact culling.
+constexpr long kTeamMaxTiles = 4096;
+constexpr float kTeamMinRadiusPx = 2.f;
+const TeamEntry* pick_team(const gendr_params* p, int texm, bool silhouette, long total_tiles, long ent_cap8)
+{
+    if (p->team < 0 || !p->cull || ent_cap8 <= 0 || p->deterministic) return nullptr;
+    const int rgb = silhouette ? kRgbNone : p->aggr_rgb_func;
+    const int sq = (p->dist_squared && p->dist_func != kHeaviside) ? 1 : 0;
+    const TeamEntry* t = nullptr;
+    for (const TeamEntry& e : kTeam)
+        if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == rgb && e.key.sq == sq && e.key.texm == texm) t = &e;
+    if (!t || p->team > 0) return t;
+    if (total_tiles > kTeamMaxTiles) return nullptr;
+    const float r = gendr_cull_radius(p);
+    return (r < 1e18f && r * (float)p->image_size * 0.5f >= kTeamMinRadiusPx) ? t : nullptr;
+}
 
 struct Workspace {
     size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, hints_off, sorted_off, loose_off, control_off, det_off, total;
@@ -323,7 +376,7 @@ int render_blocks(int total_blocks, int split_items = 0)
 
 // Waves of a render kernel the chip holds at once, per tile queue: occupancy (one-wave workgroups per CU) x CUs / 8.
 // Queried once per kernel and device.
-int resident_per_queue(render_kernel_t k)
+int resident_per_queue(render_kernel_t k, int threads = kThreads)
 {
     // (one slot per render kernel of the dispatch tables and device: ~60 kernels; a thread that fills the cache keeps querying
     // the kernels that did not fit -- ADVICE r4: 16 slots were fewer than a test session's option sets)
@@ -336,7 +389,7 @@ int resident_per_queue(render_kernel_t k)
     for (int i = 0; i < used; i++)
         if (cache[i].k == k && cache[i].dev == dev) return cache[i].v;
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), kThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), threads, 0) != hipSuccess || per_cu <= 0) per_cu = threads == kThreads ? 16 : 2;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     (void)hipGetLastError();
     const int v = per_cu * cus / 8;
@@ -353,6 +406,15 @@ int split_budget(const gendr_params* p, int texm, bool silhouette)
     const KernelEntry& k = pick_kernel(p, texm, silhouette);
     const int r = std::min(resident_per_queue(k.fwd), resident_per_queue(k.bwd));
     return r + (r >> 2);
+}
+
+// Grid of a team kernel: the workgroups the chip holds at once (a team keeps its tile's state in LDS: a second generation of
+// workgroups would only queue behind the first), but no more than the tiles of the longest queue; team r of XCD x takes the
+// records r, r + stride, ... of queue x -- heaviest first.
+int team_blocks(render_kernel_t k, int threads, int total_tiles)
+{
+    const int per_queue = (total_tiles + 7) / 8;
+    return 8 * std::max(1, std::min(per_queue, resident_per_queue(k, threads)));
 }
 
 int check_launch()
@@ -415,6 +477,14 @@ int gendr_validate(const gendr_params* p, int B, int nf, int T)
     }
     if (tp != tp) return GENDR_E_TCONORM_PARAM;
     return GENDR_OK;
+}
+
+int gendr_uses_team(int B, int nf, int T, const gendr_params* p, int silhouette)
+{
+    if (silhouette) T = 4;                                       // kSilT: the workspace layout of the alpha-only entry points
+    if (gendr_validate(p, B, nf, T) != GENDR_OK || B == 0) return 0;
+    const Workspace w = workspace_layout(B, nf, T, p);
+    return pick_team(p, texture_mode(p, T), silhouette != 0, (long)B * w.tiles_x * w.tiles_x, w.ent_cap8) ? 1 : 0;
 }
 
 float gendr_sigmoid_forward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift)
@@ -549,6 +619,10 @@ int gendr_silhouette_forward(const float* faces, float* alpha, void* workspace, 
     a.target = target;
     a.iou_sums = iou_sums;
     a.p.background_from_buffer = 0;
+    if (const TeamEntry* tk = pick_team(p, texm, true, a.total_tiles, a.ent_cap8)) {
+        hipLaunchKernelGGL(tk->fwd, dim3(team_blocks(tk->fwd, 64 * kTeamFwdWaves, a.total_tiles)), dim3(64 * kTeamFwdWaves), 0, (hipStream_t)stream, a);
+        return check_launch();
+    }
     const KernelEntry& k = pick_kernel(p, texm, true);
     hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, true))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
@@ -575,6 +649,10 @@ int gendr_silhouette_backward(const float* alpha, const void* workspace, const f
     a.grad_textures = grad_faces;            // never written: the alpha-only kernels have no texture term
     a.p.background_from_buffer = 0;
     if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, kSilT, p, true, stream);
+    if (const TeamEntry* tk = pick_team(p, texm, true, a.total_tiles, a.ent_cap8)) {
+        hipLaunchKernelGGL(tk->bwd, dim3(team_blocks(tk->bwd, 64 * kTeamBwdWaves, a.total_tiles)), dim3(64 * kTeamBwdWaves), 0, (hipStream_t)stream, a);
+        return check_launch();
+    }
     const KernelEntry& k = pick_kernel(p, texm, true);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, true))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
@@ -764,7 +842,8 @@ static int face_setup_impl(const float* faces, const float* textures, void* work
     if (e != GENDR_OK) return e;
     // heavy tiles first: the render kernels walk the sorted copy of the queue records
     if (w.ordered) {
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderThreads), 0, s, a, split_budget(p, texm, silhouette));
+        const bool team = pick_team(p, texm, silhouette, a.total_tiles, a.ent_cap8) != nullptr;
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderThreads), 0, s, a, team ? 0 : split_budget(p, texm, silhouette), team ? 1 : 0);
         return check_launch();
     }
     return GENDR_OK;
@@ -785,6 +864,10 @@ int gendr_forward(const float* faces, const float* textures, float* rgba, float*
     const int texm = fill_args(a, workspace, textures, B, nf, T, p);
     a.rgba = rgba;
     a.aux = aggrs_info;
+    if (const TeamEntry* tk = pick_team(p, texm, false, a.total_tiles, a.ent_cap8)) {
+        hipLaunchKernelGGL(tk->fwd, dim3(team_blocks(tk->fwd, 64 * kTeamFwdWaves, a.total_tiles)), dim3(64 * kTeamFwdWaves), 0, (hipStream_t)stream, a);
+        return check_launch();
+    }
     const KernelEntry& k = pick_kernel(p, texm);
     hipLaunchKernelGGL(k.fwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, false))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();
@@ -811,6 +894,10 @@ int gendr_backward(const float* faces, const float* textures, const float* rgba,
     a.grad_textures = grad_textures;
     a.p.background_from_buffer = 0;
     if (p->deterministic) return launch_deterministic_backward(a, workspace, B, nf, T, p, false, stream);
+    if (const TeamEntry* tk = pick_team(p, texm, false, a.total_tiles, a.ent_cap8)) {
+        hipLaunchKernelGGL(tk->bwd, dim3(team_blocks(tk->bwd, 64 * kTeamBwdWaves, a.total_tiles)), dim3(64 * kTeamBwdWaves), 0, (hipStream_t)stream, a);
+        return check_launch();
+    }
     const KernelEntry& k = pick_kernel(p, texm);
     hipLaunchKernelGGL(k.bwd, dim3(render_blocks(a.total_blocks, split_budget(p, texm, false))), dim3(kThreads), 0, (hipStream_t)stream, a);
     return check_launch();

@@ -1602,14 +1602,20 @@ constexpr int kOrderThreads = 1024, kOrderClasses = 32;
 constexpr long kOrderTilesMax = 1L << 19;
 // weight class of a queue record (tile, first entry, entries, pairs): 0 = no entries at all (a tile with a slice of the pool
 // whose list came out empty), else 1 + pairs / 32, capped
-__device__ __forceinline__ int order_class(const int4& rec)
+// (shift: 5 = steps of 32 pairs; the team kernels' calls, whose live tiles hold thousands of pairs, sort in steps of 512 -- kTeamClassShift)
+__device__ __forceinline__ int order_class(const int4& rec, int shift = 5)
 {
     if (rec.y >= 0 && rec.z == 0) return 0;
-    return min((rec.w >> 5) + 1, kOrderClasses - 1);
+    return min((rec.w >> shift) + 1, kOrderClasses - 1);
 }
+#ifndef GENDR_TEAM_PIECE
+#define GENDR_TEAM_PIECE 4
+#endif
+constexpr int kTeamClassShift = 9, kTeamPieceClasses = GENDR_TEAM_PIECE;      // team calls: a tile of more than 4 x 512 pairs is cut into parts (backward)
 
-__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const RenderArgs a, int budget)
+__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const RenderArgs a, int budget, int team)
 {
+    const int shift = team ? kTeamClassShift : 5;
     __shared__ int s_count[kOrderClasses], s_cursor[kOrderClasses];
     const int x = blockIdx.x;
     const long qbase = queue_begin(x, a.total_tiles);
@@ -1617,7 +1623,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
     if (threadIdx.x < kOrderClasses) s_count[threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kOrderThreads)
-        atomicAdd(&s_count[order_class(a.tile_info_raw[qbase + i])], 1);
+        atomicAdd(&s_count[order_class(a.tile_info_raw[qbase + i], shift)], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int at = 0;
@@ -1630,7 +1636,18 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
         // split grades (see TileWalk): class c >= 1 holds the tiles of 32 (c - 1) .. 32 c - 1 pairs; a tile is split 2-, 4-, 8-fold if
         // its class exceeds tc, 2 tc, 4 tc, with the smallest tc >= 2 (pieces of 64 pairs: one batch) whose work items fit `budget`
         int g8 = 0, g4 = 0, g2 = 0;
-        if (live > 0 && live < budget) {
+        if (team) {
+            // team calls (gendr_team.h): the backward teams take a heavy tile in 2, 4 or 8 PARTS -- ranges of its batches, there is no
+            // order to keep -- of at most kTeamPieceClasses x 512 pairs or so, whatever the number of teams: the parts are dealt out
+            // heaviest tile first, so the teams' loads even out; the forward teams ignore the grades (a fold cannot be cut)
+            int n2 = 0, n4 = 0, n8 = 0;
+            for (int c = kOrderClasses - 1; c > kTeamPieceClasses; c--) {
+                n2 += s_count[c];
+                if (c > 2 * kTeamPieceClasses) n4 += s_count[c];
+                if (c > 4 * kTeamPieceClasses) n8 += s_count[c];
+            }
+            g8 = n8; g4 = n4 - n8; g2 = n2 - n4;
+        } else if (live > 0 && live < budget) {
             int above[kOrderClasses + 1];                    // above[c] = tiles of a class > c
             above[kOrderClasses] = 0;
             for (int c = kOrderClasses - 1; c >= 0; c--) above[c] = above[c + 1] + (c + 1 < kOrderClasses ? s_count[c + 1] : 0);
@@ -1646,7 +1663,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kOrderThreads) {
         const int4 rec = a.tile_info_raw[qbase + i];
-        a.tile_info[qbase + atomicAdd(&s_cursor[order_class(rec)], 1)] = rec;
+        a.tile_info[qbase + atomicAdd(&s_cursor[order_class(rec, shift)], 1)] = rec;
     }
 }
 

@@ -111,12 +111,13 @@ def make_params(image_size, background_color, dist_func, dist_scale, dist_square
     p.pool_entries_max = int(os.environ.get('GENDR_POOL_ENTRIES_MAX', '0'))
     p.pair_hints = int(os.environ.get('GENDR_PAIR_HINTS', '0'))     # 0 automatic, 1 on, -1 off (include/gendr_hip.h, ABI 6)
     p.loose_faces = int(os.environ.get('GENDR_LOOSE_FACES', '0'))   # likewise
+    p.team = int(os.environ.get('GENDR_TEAM', '0'))                 # likewise (ABI 7: team kernels)
     return p
 
 
 _CPP_AUTOGRAD = os.environ.get('GENDR_CPP_AUTOGRAD', '1') != '0'
 _PARAMS_CACHE = {}
-_ENV_KEYS = ('GENDR_TEXEL_MODE', 'GENDR_CULL', 'GENDR_DETERMINISTIC', 'GENDR_POOL_ENTRIES_MAX', 'GENDR_PAIR_HINTS', 'GENDR_LOOSE_FACES',
+_ENV_KEYS = ('GENDR_TEXEL_MODE', 'GENDR_CULL', 'GENDR_DETERMINISTIC', 'GENDR_POOL_ENTRIES_MAX', 'GENDR_PAIR_HINTS', 'GENDR_LOOSE_FACES', 'GENDR_TEAM',
              'GENDR_SKIP_UNLISTED_AUX', 'GENDR_FUSED_CLEAR')
 
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GENDR_ABI_VERSION 6
+#define GENDR_ABI_VERSION 7
 
 enum {
     GENDR_OK              = 0,
@@ -103,6 +103,17 @@ typedef struct gendr_params {
                                       own first narrows the boxes of such faces, per-image lists in the workspace); -1: off;
                                       2: on, with that launch and its lists at EVERY image size (what 1024^2 and more take by default:
                                       lets small test images exercise it). */
+    /* ---- ABI 7 ---- */
+    int   team;                    /* Team kernels: where few tiles each hold thousands of (pixel, face) pairs -- small images, few
+                                      views, a distribution whose tail spans pixels: the reference's experiments/opt_shape.py
+                                      renders 24 views at 64^2 with a 4-pixel logistic tail -- one workgroup of nine (forward) or
+                                      eight (backward) wavefronts renders a tile: the tile's pair list is built once, in shared
+                                      LDS, its batches of 64 pairs are evaluated by eight wavefronts side by side, and (forward)
+                                      a ninth folds their results per pixel in the reference's order.  Results do not depend on
+                                      it (forward bit for bit).  0 (default): on for the option sets that have a team kernel
+                                      (the logistic ones) when the call holds at most 4096 tiles and the cull radius is at
+                                      least 2 pixels; 1: on wherever a team kernel exists; -1: off.  gendr_forward and
+                                      gendr_backward must be called with the same setting (the pair hints depend on it). */
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward
@@ -115,6 +126,10 @@ unsigned long long gendr_workspace_bytes(int B, int nf, int T, const gendr_param
 
 /* Validates the option set exactly as the reference's asserts / device checks do. */
 int gendr_validate(const gendr_params* p, int B, int nf, int T);
+
+/* 1 if gendr_forward / gendr_backward (silhouette != 0: gendr_silhouette_forward / _backward) render this call with the team
+ * kernels (gendr_params::team), else 0.  A host-side decision on the shapes and the option set only; for tests and reports. */
+int gendr_uses_team(int B, int nf, int T, const gendr_params* p, int silhouette);
 
 /* Per-face preprocessing into this build's record layout (replaces forward_render_inv_cuda_kernel,
  * kernel.cu:620-676, launched at :1100-1109) followed by the tile binning of the exact culling.

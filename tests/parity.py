@@ -16,7 +16,7 @@ DEFAULTS = dict(dist_func='uniform', dist_scale=1e-2, dist_squared=False, dist_s
 
 def split_options(opts):
     o = dict(DEFAULTS)
-    extra = dict(background=(0., 0., 0.), texel_mode=0, T=1, cull=1, deterministic=0, pool_entries_max=0, skip_unlisted_aux=0, pair_hints=0, loose_faces=0)
+    extra = dict(background=(0., 0., 0.), texel_mode=0, T=1, cull=1, deterministic=0, pool_entries_max=0, skip_unlisted_aux=0, pair_hints=0, loose_faces=0, team=0)
     for k, v in opts.items():
         if k in extra:
             extra[k] = v
@@ -34,6 +34,7 @@ def hip_params(image_size, o, extra):
     p.skip_unlisted_aux = extra['skip_unlisted_aux']
     p.pair_hints = extra['pair_hints']
     p.loose_faces = extra['loose_faces']
+    p.team = extra['team']
     return p
 
 
