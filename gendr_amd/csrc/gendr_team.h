@@ -74,18 +74,24 @@ template <int NB>
 __device__ __forceinline__ void team_build(const int4* __restrict__ ents, int cnt, int& e_next, int& built, int consumed, int* s_ring, int w,
                                            int first_code = 0, int end_code = 0x7fffffff, unsigned long long pixels = ~0ull)
 {
-    // `pixels`: the pixel rows of the tile the caller renders (a row part, forward): the entries' masks are cut to them
     // [first_code, end_code): the codes the caller will read (a PART of the tile's list, backward) -- rounds that end before the range
-    // are scanned, not expanded, and nothing is built past its end
+    // are scanned, not expanded, and nothing is built past its end.
+    // `pixels`: the pixel rows of the tile the caller renders (a row part, forward): the entries' masks are cut to them.
+    // The entries of the following round are requested before the current one is expanded (a round is one L2 round trip otherwise).
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    while (e_next < cnt && built < end_code && built - consumed + kTeamRound * 64 <= kTeamRing) {
+    auto more = [&]() { return e_next < cnt && built < end_code && built - consumed + kTeamRound * 64 <= kTeamRing; };
+    if (!more()) return;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (lane < min(kTeamRound, cnt - e_next)) e = ents[e_next + lane];
+    do {
         const int n = min(kTeamRound, cnt - e_next);
-        int4 e = make_int4(0, 0, 0, 0);
-        if (lane < n) e = ents[e_next + lane];
-        int total;
+        int4 e_ahead = make_int4(0, 0, 0, 0);
+        if (lane < min(kTeamRound, cnt - e_next - n)) e_ahead = ents[e_next + n + lane];
         const unsigned long long mine = (((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z) & pixels;     // (lanes >= n hold zeros)
-        const int pos = wave_exclusive_scan(__popcll(mine), total);
+        const int np = __popcll(mine);
+        const int pos = wave_exclusive_scan_dpp(np);
+        const int total = __builtin_amdgcn_readlane(pos + np, 63);
         if (w >= 0 && built + total > first_code) {
             for (int j = w; j < n; j += NB) {
                 const int fn = __builtin_amdgcn_readlane(e.x, j);
@@ -96,7 +102,8 @@ __device__ __forceinline__ void team_build(const int4* __restrict__ ents, int cn
         }
         built += total;
         e_next += n;
-    }
+        e = e_ahead;
+    } while (more());
 }
 
 // per-pixel state of the forward fold, kernel.cu:728-740
@@ -443,7 +450,7 @@ void render_forward_team_kernel(const RenderArgs a)
                         if (c + kTeamB + wb < nb) announce(k + kTeamB, (chunk_ctr + 1) % 3);
                     }
                     __syncthreads();                                     // chunk c is evaluated; the B-waves go on to chunk c + 1
-                    if (folder) {
+                    if (folder && GENDR_TEAM_ABLATE != 6) {
                         // ---- phase C: every pixel folds its pairs of the chunk: consecutive slots, ascending list order = ascending
                         // face order; the next result is requested before the current one is folded
                         int total;
