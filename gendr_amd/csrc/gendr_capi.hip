@@ -159,11 +159,16 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" float gendr_cull_radius(const gendr_params* p);
 
-// gendr_params::team.  Automatic: the call holds at most kTeamMaxTiles tiles and the cull radius is at least kTeamMinRadiusPx
-// pixels -- few tiles, each listing a face for every pixel within that radius (opt_shape.py: 1 536 tiles, 4.4 pixels, 4 000 pairs per
-// live tile: forward 169 -> us, backward 170 -> us per call); with many tiles or short tails one wave per tile is the
-// better shape.  Needs the entry pool (the team walks coverage entries) and the exact culling.
-constexpr long kTeamMaxTiles = 4096;
+// gendr_params::team.  Automatic: the call holds at most kTeamMaxTilesShort tiles, or at most kTeamMaxTiles and the cull radius is at
+// least kTeamMinRadiusPx pixels -- few tiles, each listing a face for every pixel within that radius.  Measured (tools/teamrule*.sh, one MI355X, forward +
+// backward call, one-wave kernels -> team kernels): opt_shape.py's shape (24 views of 64^2, sigma 1e-2: 1 536 tiles, 4.4 pixels, 4 000
+// pairs per live tile) 0.406 -> 0.234 ms; 8 views 0.333 -> 0.167; 128 views (8 192 tiles) 1.07 -> 0.86; sigma 3e-2 (pixel-mode tiles)
+// 1.75 -> 0.87; 128^2 x 16 0.53 -> 0.39; 256^2 x 8 (BASELINE config 4's regime at a strong-scaling share) 0.76 -> 0.54; at 16 384 tiles
+// the two are level, from 32 768 tiles the one-wave kernels win (512^2 x 32: 4.3 against 6.9 ms) -- with thousands of tiles in flight
+// every SIMD has its waves and a team's barriers only cost.  A team kernel for BASELINE config 2's option set (244 pairs per tile)
+// was measured too: backward -20 % up to 4 096 tiles, forward level, slower from 8 192 -- not built in.  Needs the entry pool (the
+// team walks coverage entries) and the exact culling.
+constexpr long kTeamMaxTiles = 8192, kTeamMaxTilesShort = 4096;
 constexpr float kTeamMinRadiusPx = 2.f;
 const TeamEntry* pick_team(const gendr_params* p, int texm, bool silhouette, long total_tiles, long ent_cap8)
 {
@@ -174,6 +179,9 @@ const TeamEntry* pick_team(const gendr_params* p, int texm, bool silhouette, lon
     for (const TeamEntry& e : kTeam)
         if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == rgb && e.key.sq == sq && e.key.texm == texm) t = &e;
     if (!t || p->team > 0) return t;
+    // up to 4 096 tiles whatever the tail (opt_shape.py sweeps sigma down to 1e-7 at 1 536 tiles: 0.095 -> 0.076 ms at sigma 1e-4 -- light
+    // tiles, the gain is the backward call's), up to 8 192 where a tile holds pairs by the thousand
+    if (total_tiles <= kTeamMaxTilesShort) return t;
     if (total_tiles > kTeamMaxTiles) return nullptr;
     const float r = gendr_cull_radius(p);
     return (r < 1e18f && r * (float)p->image_size * 0.5f >= kTeamMinRadiusPx) ? t : nullptr;

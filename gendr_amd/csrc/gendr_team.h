@@ -21,8 +21,13 @@
 //     face, component), exactly the unsplit kernel's batch.
 // The pair functions are the ones every other path uses (barycentrics(), soft_fragment(), clip_and_depth(), sample_colour(),
 // backward_pair()) on the same operands: forward results are bit-identical to the one-wave kernels' and to the all-pairs walk.
-// Tiles the team does not suit -- pixel-mode tiles (entries of 36 pixels and more: lane = pixel without a list is cheaper) and
-// tiles without a slice of the entry pool -- are rendered by one wave of the team with the dense (lane = pixel, scalar record) path.
+// Tiles of nearly full entries (36 pixels and more on average: the one-wave kernels' pixel mode) are rendered by the team with
+// lane = pixel: a chunk is eight ENTRIES, one per B-wave, each evaluated on all 64 pixels with the face's record in scalar registers,
+// folded entry by entry (backward: the entries dealt out to the eight waves).  A tile without a slice of the entry pool is rendered by
+// one wave of the team with the all-faces walk.
+//
+// Measured (one MI355X, opt_shape.py's shape, 3.3 M pairs): forward kernel 169 -> 88 us, backward kernel 170 -> 88 us; what the stages
+// of the design were worth is in DESIGN.md.
 #pragma once
 
 #include "gendr_kernels.h"
@@ -179,7 +184,6 @@ template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(64 * kTeamFwdWaves) __attribute__((amdgpu_waves_per_eu(GENDR_FWD_WAVES)))
 void render_forward_team_kernel(const RenderArgs a)
 {
-    static_assert(dense_path<DIST>(), "the team's solo path is the dense (lane = pixel) evaluation");
     constexpr int REC = record_floats(TEXM);
     constexpr bool kSil = RGB == kRgbNone;
     __shared__ int s_ring[kTeamRing];
@@ -288,7 +292,8 @@ void render_forward_team_kernel(const RenderArgs a)
         TileCtx t;
         tile_setup(t, a, ti.x);
         const float* recs_g = a.records + (long)t.b * a.nf * REC;
-        const bool solo = ti.y < 0 || tile_in_pixel_mode(ti, 0);         // one wave, lane = pixel: no pool slice, or nearly full entries
+        const bool solo = ti.y < 0;                                      // one wave, lane = pixel: the tile has no slice of the entry pool
+        const bool dense_tile = !solo && tile_in_pixel_mode(ti, 0);      // nearly full entries: lane = pixel, an entry per B-wave
         t.valid = t.valid && ((my_rows >> lane) & 1ull);                 // the pixels this team renders
 
         FwdPix px;
@@ -306,49 +311,66 @@ void render_forward_team_kernel(const RenderArgs a)
             px.face_min = -1;
         }
 
+        // lane = pixel, the face's record in scalar registers (run_dense of render_forward_body): the result of (face, this lane's pixel)
+        auto dense_eval = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) -> TeamRes {
+            const long face_lin = (long)t.b * a.nf + fn;
+            const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
+            float r[REC];
+            RecPtr rs = uniform_rec_ptr(recs_g + (long)fn * REC);
+            load_record<4 * kGatherW0, 4 * kGatherW1>(r, rs);
+            Pair q;
+            barycentrics(q, r, t.xp, t.yp);
+            asm volatile("" : "+s"(rs) : "v"(q.w0), "v"(q.w1), "v"(q.w2));
+            load_record<4 * kGatherA0, 4 * kGatherA1>(r, rs);
+            TeamRes res;
+            res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fnflags = fn << 3;
+            bool contributes = false;
+            q.frag = 0.f;
+            if (mine) contributes = soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp, false, tag == 1, tag == 2, tag != 0);
+            if constexpr (!kSil) {
+                asm volatile("" : "+s"(rs) : "v"(q.frag));
+                load_record<4 * kGatherB0, REC>(r, rs);
+            }
+            if (contributes) team_depth_colour<RGB, TEXM>(res, fn, q, r, a, rgb_soft, face_lin);
+            return res;
+        };
         if (solo) {
             if (!folder) continue;
-            // lane = pixel, the face's record in scalar registers, folded in place (run_dense of render_forward_body)
-            auto dense = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) {
-                const long face_lin = (long)t.b * a.nf + fn;
-                const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
-                float r[REC];
-                RecPtr rs = uniform_rec_ptr(recs_g + (long)fn * REC);
-                load_record<4 * kGatherW0, 4 * kGatherW1>(r, rs);
+            // pool exhausted: the exact per-pixel tests for every face of the image (collect_pairs), as for_each_batch's fallback,
+            // evaluated and folded in place by the fold wave alone
+            const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
+            for (int fn = 0; fn < a.nf; fn++) {
                 Pair q;
-                barycentrics(q, r, t.xp, t.yp);
-                asm volatile("" : "+s"(rs) : "v"(q.w0), "v"(q.w1), "v"(q.w2));
-                load_record<4 * kGatherA0, 4 * kGatherA1>(r, rs);
-                TeamRes res;
-                res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fnflags = fn << 3;
-                bool contributes = false;
-                q.frag = 0.f;
-                if (mine) contributes = soft_fragment<DIST, SQ>(q, r, t.xp, t.yp, a, dp, false, tag == 1, tag == 2, tag != 0);
-                if constexpr (!kSil) {
-                    asm volatile("" : "+s"(rs) : "v"(q.frag));
-                    load_record<4 * kGatherB0, REC>(r, rs);
+                const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
+                if (m) team_fold<ALPHA, RGB>(px, dense_eval(fn, m, 0), a, alpha_func, rgb_soft);
+            }
+        } else if (dense_tile) {
+            // PIXEL MODE for a team (for_each_batch: entries of kPixelModeAvg pixels and more on average -- no pair list pays): a chunk
+            // is eight ENTRIES, B-wave w evaluates entry c + w on all 64 pixels (lane = pixel, the record in scalar registers) into
+            // slots [64 w, 64 w + 64) of the chunk's result buffer, and the fold wave folds slots lane, 64 + lane, ... in order while the
+            // B-waves evaluate the next eight entries.
+            const GENDR_CONST_AS i4v* ents = (const GENDR_CONST_AS i4v*)(a.entries + ti.y);
+            const int cnt = ti.z;
+            for (int c = 0; c < cnt; c += kTeamB, chunk_ctr++) {
+                const int buf = chunk_ctr & 1;
+                if (!folder && c + wb < cnt) {
+                    const i4v e = ents[c + wb];                          // (face, npix | tag << 8, mask lo, mask hi): scalar load
+                    const unsigned long long m = ((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z;
+                    s_res[buf][wb * 64 + lane] = dense_eval(e.x, m & my_rows, (e.y >> 8) & 3);
                 }
-                if (contributes) team_depth_colour<RGB, TEXM>(res, fn, q, r, a, rgb_soft, face_lin);
-                team_fold<ALPHA, RGB>(px, res, a, alpha_func, rgb_soft);
-            };
-            if (ti.y >= 0) {
-                const int4* ents = reinterpret_cast<const int4*>(a.entries + ti.y);
-                for (int e0 = 0; e0 < ti.z; e0 += 64) {
-                    const int n = min(64, ti.z - e0);
-                    int4 e = make_int4(0, 0, 0, 0);
-                    if (lane < n) e = ents[e0 + lane];
-                    for (int j = 0; j < n; j++) {
-                        const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j);
-                        dense(__builtin_amdgcn_readlane(e.x, j), m, (__builtin_amdgcn_readlane(e.y, j) >> 8) & 3);
+                __syncthreads();
+                if (folder) {
+                    const int n = min(kTeamB, cnt - c);
+                    for (int j0 = 0; j0 < n; j0 += 4) {
+                        TeamRes r4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            r4[j].frag = 0.f; r4[j].z = 0.f; r4[j].c0 = r4[j].c1 = r4[j].c2 = 0.f; r4[j].fnflags = 0;
+                            if (j0 + j < n) r4[j] = s_res[buf][(j0 + j) * 64 + lane];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) team_fold<ALPHA, RGB>(px, r4[j], a, alpha_func, rgb_soft);
                     }
-                }
-            } else {
-                // pool exhausted: the exact per-pixel tests for every face of the image (collect_pairs), as for_each_batch's fallback
-                const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
-                for (int fn = 0; fn < a.nf; fn++) {
-                    Pair q;
-                    const unsigned long long m = collect_pairs<REC>(t, recs + (long)fn * REC, q);
-                    if (m) dense(fn, m, 0);
                 }
             }
         } else {
@@ -519,7 +541,6 @@ template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(64 * kTeamBwdWaves) __attribute__((amdgpu_waves_per_eu(GENDR_BWD_WAVES)))
 void render_backward_team_kernel(const RenderArgs a)
 {
-    static_assert(dense_path<DIST>(), "the team's solo path is the dense (lane = pixel) evaluation");
     constexpr int REC = record_floats(TEXM);
     constexpr int NG = GradSlots<TEXM>::n;
     constexpr int NT = NG > 9 ? NG - 9 : 1;
@@ -545,16 +566,17 @@ void render_backward_team_kernel(const RenderArgs a)
         const int slot_i = walk_item(tw, item, part_log2, part);
         const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + slot_i));
         if (ti.y >= 0 && ti.z == 0) continue;                           // an empty coverage list (no heavy-first copy)
-        const bool solo = ti.y < 0 || tile_in_pixel_mode(ti, 0);
+        const bool solo = ti.y < 0;                                     // no slice of the entry pool: wave 0 alone walks all faces
+        const bool dense_tile = !solo && tile_in_pixel_mode(ti, 0);     // nearly full entries: lane = pixel, the entries dealt out to the waves
         if (solo && (wave != 0 || part != 0)) continue;                 // (a solo tile is not cut: its first part is all of it)
         TileCtx t;
         tile_setup(t, a, ti.x);
         const float* recs_g = a.records + (long)t.b * a.nf * REC;
         if (wave == 0) s_pix[lane] = load_pixel_inputs<RGB>(a, t.b, t.pix, t.valid, t.xp, t.yp);
 
-        if (solo) {
-            // wave 0 alone, lane = pixel, the ONE face's partials summed by four lanes per component (run_dense of render_backward_body)
-            __builtin_amdgcn_wave_barrier();
+        if (solo || dense_tile) {
+            // lane = pixel, the ONE face's partials summed by four lanes per component (run_dense of render_backward_body)
+            if (dense_tile) __syncthreads(); else __builtin_amdgcn_wave_barrier();       // s_pix is written
             const PixIn px = s_pix[lane];
             auto dense = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) {
                 const long face_lin = (long)t.b * a.nf + fn;
@@ -575,16 +597,16 @@ void render_backward_team_kernel(const RenderArgs a)
 #pragma unroll
                 for (int k = 0; k < NG - 9; k++) asm("" : "+v"(gt[k]));
 #pragma unroll
-                for (int k = 0; k < 9; k++) s_val[0][k * 65 + lane] = live ? gv[k] : 0.f;
+                for (int k = 0; k < 9; k++) s_val[wave][k * 65 + lane] = live ? gv[k] : 0.f;
 #pragma unroll
-                for (int k = 0; k < NG - 9; k++) s_val[0][(9 + k) * 65 + lane] = live ? gt[k] : 0.f;
+                for (int k = 0; k < NG - 9; k++) s_val[wave][(9 + k) * 65 + lane] = live ? gt[k] : 0.f;
                 __builtin_amdgcn_wave_barrier();
                 constexpr int PER = NG <= 16 ? 4 : 2;
                 constexpr int LEN = 64 / PER;
                 const int k = lane / PER, seg = lane % PER;
                 float v = 0.f;
                 if (k < NG) {
-                    const float* col = &s_val[0][k * 65 + seg * LEN];
+                    const float* col = &s_val[wave][k * 65 + seg * LEN];
                     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
 #pragma unroll
                     for (int i = 0; i < LEN; i += 4) { v0 += col[i]; v1 += col[i + 1]; v2 += col[i + 2]; v3 += col[i + 3]; }
@@ -598,18 +620,19 @@ void render_backward_team_kernel(const RenderArgs a)
                 }
                 __builtin_amdgcn_wave_barrier();
             };
-            if (ti.y >= 0) {
-                const int4* ents = reinterpret_cast<const int4*>(a.entries + ti.y);
-                for (int e0 = 0; e0 < ti.z; e0 += 64) {
-                    const int n = min(64, ti.z - e0);
-                    int4 e = make_int4(0, 0, 0, 0);
-                    if (lane < n) e = ents[e0 + lane];
-                    for (int j = 0; j < n; j++) {
-                        const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j);
-                        dense(__builtin_amdgcn_readlane(e.x, j), m, (__builtin_amdgcn_readlane(e.y, j) >> 8) & 3);
-                    }
+            if (dense_tile) {
+                // PIXEL MODE for a team: backward keeps no order, so this part's share of the tile's entries is dealt out to the eight
+                // waves, each evaluating its entries on all 64 pixels
+                const GENDR_CONST_AS i4v* ents = (const GENDR_CONST_AS i4v*)(a.entries + ti.y);
+                const int e_lo = (int)(((long)part * ti.z) >> part_log2), e_hi = (int)(((long)(part + 1) * ti.z) >> part_log2);
+                for (int j = e_lo + wave; j < e_hi; j += kTeamBwdWaves) {
+                    const i4v e = ents[j];
+                    dense(e.x, ((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z, (e.y >> 8) & 3);
                 }
-            } else {
+                __syncthreads();                                         // every wave has read s_pix
+                continue;
+            }
+            {
                 const RecPtr recs = (RecPtr)a.records + (long)t.b * a.nf * REC;
                 for (int fn = 0; fn < a.nf; fn++) {
                     Pair q;

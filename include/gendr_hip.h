@@ -111,9 +111,10 @@ typedef struct gendr_params {
                                       LDS, its batches of 64 pairs are evaluated by eight wavefronts side by side, and (forward)
                                       a ninth folds their results per pixel in the reference's order.  Results do not depend on
                                       it (forward bit for bit).  0 (default): on for the option sets that have a team kernel
-                                      (the logistic ones) when the call holds at most 4096 tiles and the cull radius is at
-                                      least 2 pixels; 1: on wherever a team kernel exists; -1: off.  gendr_forward and
-                                      gendr_backward must be called with the same setting (the pair hints depend on it). */
+                                      (logistic / probabilistic, surface texture with T = 1, and its alpha-only twin) when the
+                                      call holds at most 4096 tiles (8192 with a cull radius of 2 pixels and more); 1: on wherever a
+                                      team kernel exists; -1: off.  gendr_forward and gendr_backward must be called with the
+                                      same setting (the pair hints depend on it); ignored with `deterministic`. */
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward

@@ -33,12 +33,13 @@ def _entries(ws, B, nf, isz, rec_floats):
     return np.concatenate(rows), ents
 
 
+@pytest.mark.parametrize("team", [-1, 1])          # the one-wave kernels' paths, and the team kernels' (round 5: automatic at this size)
 @pytest.mark.parametrize("rgb", ['softmax', 'hard'])
-def test_pixel_mode_dense_entries_and_region_tags(oracle_mod, native_lib, rgb):
+def test_pixel_mode_dense_entries_and_region_tags(oracle_mod, native_lib, rgb, team):
     from gendr_amd.functional import renderer as R
     fv, tex = scenes.sphere(B=2)
     isz = 64
-    opts = dict(OPTS, aggr_rgb_func=rgb)
+    opts = dict(OPTS, aggr_rgb_func=rgb, team=team)
     grad = np.random.RandomState(2).randn(fv.shape[0], 4, isz, isz).astype(np.float32)
     # the paths are taken: read the coverage entries back
     o, extra = parity.split_options(opts)

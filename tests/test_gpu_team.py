@@ -27,12 +27,14 @@ def _uses_team(B, nf, T, isz, opts, silhouette=0):
 
 
 def test_the_rule(native_lib):
-    """Automatic: an option set with a team kernel, at most 4096 tiles, a cull radius of 2 pixels and more."""
+    """Automatic: an option set with a team kernel and at most 4096 tiles, or 8192 with a cull radius of 2 pixels and more."""
     assert _uses_team(24, 1280, 1, 64, SOFT) == 1                                   # opt_shape.py: 1536 tiles, 4.4 pixels
     assert _uses_team(24, 1280, 1, 64, dict(SOFT, aggr_rgb_func='softmax')) == 1
     assert _uses_team(24, 1280, 1, 64, SOFT, silhouette=1) == 1
     assert _uses_team(24, 1280, 1, 64, dict(SOFT, team=-1)) == 0
-    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_scale=1e-4)) == 0           # 0.04 pixels
+    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_scale=1e-4)) == 1           # 0.04 pixels: few tiles are enough
+    assert _uses_team(64, 1280, 1, 64, dict(SOFT, dist_scale=1e-4)) == 1 and _uses_team(65, 1280, 1, 64, dict(SOFT, dist_scale=1e-4)) == 0
+    assert _uses_team(128, 1280, 1, 64, SOFT) == 1 and _uses_team(129, 1280, 1, 64, SOFT) == 0     # 8192 tiles and one more image
     assert _uses_team(256, 1280, 1, 512, dict(SOFT, dist_eps=1e4)) == 0             # BASELINE config 4: a million tiles
     assert _uses_team(256, 1280, 1, 512, dict(SOFT, dist_eps=1e4, team=1)) == 1     # ... forced
     assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='uniform')) == 0        # no team kernel for the option set
@@ -96,9 +98,9 @@ def test_team_with_and_without_pair_hints(native_lib, hints):
     _close_grads(t, w, 'one-wave kernels')
 
 
-def test_team_solo_paths(oracle_mod, native_lib):
-    """Pixel-mode tiles (entries of 36 pixels and more on average: sigma 3e-2 on the 80-face sphere) and tiles without a slice of
-    the entry pool (pool capped at a few entries) are rendered by one wave of the team, lane = pixel."""
+def test_team_pixel_mode_and_solo_paths(oracle_mod, native_lib):
+    """Pixel-mode tiles (entries of 36 pixels and more on average: sigma 3e-2 on the 80-face sphere) are rendered with lane = pixel,
+    an entry per B-wave; tiles without a slice of the entry pool (pool capped at a few entries) by one wave of the team."""
     fv, tex = scenes.sphere(B=2)
     isz = 64
     grad = np.random.RandomState(7).randn(2, 4, isz, isz).astype(np.float32)
