@@ -99,6 +99,9 @@ const TeamEntry kTeam[] = {
     GENDR_TEAM_ROW(kLogistic, kProbabilistic, kRgbNone, 0, kTexSurfaceN),   // the alpha-only twin
 #endif
 };
+// ... and the runtime-dispatch row of the 13 light distributions x 5 light aggregators (surface texture, T = 1): what opt_shape.py
+// renders with any other --dist-func / --aggr-func of those (key: the classes of kGeneric)
+const TeamEntry kTeamGeneric = { {-2, -2, -1, -1, kTexSurface1}, render_forward_team_kernel_wl<-2, -2, -1, -1, kTexSurface1>, render_backward_team_kernel<-2, -2, -1, -1, kTexSurface1> };
 
 #if !GENDR_DEV_MIN
 // alpha-only runtime-dispatch kernels, by the same four classes as kGeneric
@@ -178,7 +181,17 @@ const TeamEntry* pick_team(const gendr_params* p, int texm, bool silhouette, lon
     const TeamEntry* t = nullptr;
     for (const TeamEntry& e : kTeam)
         if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == rgb && e.key.sq == sq && e.key.texm == texm) t = &e;
+    bool generic = false;
+    if (!t && !silhouette && texm == kTexSurface1 && is_light_dist(p->dist_func) && is_light_alpha(p->aggr_alpha_func) && p->dist_func != kHeaviside) {
+        t = &kTeamGeneric;
+        generic = true;
+    }
     if (!t || p->team > 0) return t;
+    // an option set with a specialised one-wave kernel keeps it unless it has a specialised team kernel too: the runtime-dispatch team
+    // kernel pays ~30 % per pair for its branches (measured at BASELINE config 2's option set, 256^2 x 4: forward 49 -> 65 us)
+    if (generic)
+        for (const KernelEntry& e : kSpecialised)
+            if (e.key.dist == p->dist_func && e.key.alpha == p->aggr_alpha_func && e.key.rgb == rgb && e.key.sq == sq && e.key.texm == texm) return nullptr;
     // up to 4 096 tiles whatever the tail (opt_shape.py sweeps sigma down to 1e-7 at 1 536 tiles: 0.095 -> 0.076 ms at sigma 1e-4 -- light
     // tiles, the gain is the backward call's), up to 8 192 where a tile holds pairs by the thousand
     if (total_tiles <= kTeamMaxTilesShort) return t;

@@ -181,8 +181,7 @@ __device__ __forceinline__ void team_depth_colour(TeamRes& res, int fn, const Pa
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
-__global__ __launch_bounds__(64 * kTeamFwdWaves) __attribute__((amdgpu_waves_per_eu(GENDR_FWD_WAVES)))
-void render_forward_team_kernel(const RenderArgs a)
+__device__ __forceinline__ void team_forward_body(const RenderArgs& a)
 {
     constexpr int REC = record_floats(TEXM);
     constexpr bool kSil = RGB == kRgbNone;
@@ -537,6 +536,21 @@ void render_forward_team_kernel(const RenderArgs a)
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
+// register budgets: the specialised option sets run three teams per CU (seven waves per SIMD: 72 registers, as the one-wave kernel _w6);
+// the runtime-dispatch kernel of the light distributions x light aggregators two (five waves: 96 registers, as _wl)
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(64 * kTeamFwdWaves) __attribute__((amdgpu_waves_per_eu(GENDR_FWD_WAVES)))
+void render_forward_team_kernel(const RenderArgs a)
+{
+    team_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
+__global__ __launch_bounds__(64 * kTeamFwdWaves) __attribute__((amdgpu_waves_per_eu(GENDR_LIGHT_FWD_WAVES)))
+void render_forward_team_kernel_wl(const RenderArgs a)
+{
+    team_forward_body<DIST, ALPHA, RGB, SQ, TEXM>(a);
+}
+
 template <int DIST, int ALPHA, int RGB, int SQ, int TEXM>
 __global__ __launch_bounds__(64 * kTeamBwdWaves) __attribute__((amdgpu_waves_per_eu(GENDR_BWD_WAVES)))
 void render_backward_team_kernel(const RenderArgs a)

@@ -37,8 +37,14 @@ def test_the_rule(native_lib):
     assert _uses_team(128, 1280, 1, 64, SOFT) == 1 and _uses_team(129, 1280, 1, 64, SOFT) == 0     # 8192 tiles and one more image
     assert _uses_team(256, 1280, 1, 512, dict(SOFT, dist_eps=1e4)) == 0             # BASELINE config 4: a million tiles
     assert _uses_team(256, 1280, 1, 512, dict(SOFT, dist_eps=1e4, team=1)) == 1     # ... forced
-    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='uniform')) == 0        # no team kernel for the option set
-    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='uniform', team=1)) == 0
+    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='gaussian')) == 1       # the runtime-dispatch team kernel: light distributions
+    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='gamma', dist_shape=2.)) == 0          # ... not the heavy ones,
+    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='gamma', dist_shape=2., team=1)) == 0
+    assert _uses_team(24, 1280, 1, 64, dict(SOFT, aggr_alpha_func='yager', aggr_alpha_t_conorm_p=2.)) == 0   # nor the heavy aggregators,
+    assert _uses_team(24, 1280, 3, 64, dict(SOFT, dist_func='gaussian', texture_type='vertex')) == 0         # nor vertex textures
+    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='cauchy')) == 0         # no cull radius: no entry pool, nothing for a team to walk
+    assert _uses_team(4, 1280, 1, 256, dict()) == 0 and _uses_team(4, 1280, 1, 256, dict(team=1)) == 1   # BASELINE config 2's option set keeps
+    assert _uses_team(24, 1280, 1, 64, dict(SOFT, dist_func='uniform')) == 0        # its specialised one-wave kernel, train_reconstruction.py's too
     assert _uses_team(24, 1280, 1, 64, dict(SOFT, cull=0)) == 0
     assert _uses_team(24, 1280, 1, 64, dict(SOFT, deterministic=1)) == 0
 
@@ -79,6 +85,36 @@ def test_team_changes_nothing(oracle_mod, native_lib, name, make, rgb):
     t = parity.run_hip(fv, tex, isz, dict(opts, team=1), grad)
     w = parity.run_hip(fv, tex, isz, dict(opts, team=-1), grad)                # one wave per tile (piece)
     n = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)                 # the reference's own traversal
+    _same_forward(t, w, 'one-wave kernels')
+    _same_forward(t, n, 'all pairs')
+    _close_grads(t, w, 'one-wave kernels')
+    _close_grads(t, n, 'all pairs')
+    bad, _, _ = criteria.check_case(fv, tex, isz, opts, t, grad)
+    assert not bad, bad
+
+
+GENERIC = [
+    ('gaussian_prob_hard', dict(dist_func='gaussian', dist_scale=1e-2, aggr_rgb_func='hard')),
+    ('gauss_sq_einstein_softmax', dict(dist_func='gaussian', dist_squared=True, dist_scale=3e-4, aggr_alpha_func='einstein', aggr_rgb_func='softmax')),
+    ('laplace_hamacher_hard', dict(dist_func='laplace', dist_scale=1e-2, aggr_alpha_func='hamacher', aggr_alpha_t_conorm_p=0.5, aggr_rgb_func='hard')),
+    ('cubic_max_softmax', dict(dist_func='cubic_hermite', dist_scale=5e-2, aggr_alpha_func='max', aggr_rgb_func='softmax')),
+    ('uniform_max_hard', dict(dist_func='uniform', dist_scale=3e-2, aggr_alpha_func='max', aggr_rgb_func='hard')),
+    ('gumbelmin_prob_softmax', dict(dist_func='gumbel_min', dist_scale=1e-2, aggr_rgb_func='softmax')),
+]
+
+
+@pytest.mark.parametrize("name,o", GENERIC, ids=[g[0] for g in GENERIC])
+def test_runtime_dispatch_team_kernel(oracle_mod, native_lib, name, o):
+    """The team kernel of the 13 light distributions x 5 light aggregators (what opt_shape.py renders with any other --dist-func /
+    --aggr-func of those): against the one-wave runtime-dispatch kernels, the all-pairs traversal and the oracle."""
+    fv, tex = parity_scene(3)
+    isz = 64
+    opts = dict(dist_eps=100., double_side=False, **o)
+    grad = np.random.RandomState(9).randn(3, 4, isz, isz).astype(np.float32)
+    assert _uses_team(3, fv.shape[1], 1, isz, opts) == 1
+    t = parity.run_hip(fv, tex, isz, dict(opts, team=1), grad)
+    w = parity.run_hip(fv, tex, isz, dict(opts, team=-1), grad)
+    n = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
     _same_forward(t, w, 'one-wave kernels')
     _same_forward(t, n, 'all pairs')
     _close_grads(t, w, 'one-wave kernels')
