@@ -111,7 +111,7 @@ def test_runtime_dispatch_team_kernel(oracle_mod, native_lib, name, o):
     isz = 64
     opts = dict(dist_eps=100., double_side=False, **o)
     grad = np.random.RandomState(9).randn(3, 4, isz, isz).astype(np.float32)
-    assert _uses_team(3, fv.shape[1], 1, isz, opts) == 1
+    assert _uses_team(3, fv.shape[1], 1, isz, dict(opts, team=1)) == 1         # (forced: BASELINE config 3's option set has a specialised one-wave kernel)
     t = parity.run_hip(fv, tex, isz, dict(opts, team=1), grad)
     w = parity.run_hip(fv, tex, isz, dict(opts, team=-1), grad)
     n = parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
