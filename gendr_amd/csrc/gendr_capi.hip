@@ -62,11 +62,15 @@ struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; faces_kernel_t det
 #endif
 // -DGENDR_DEV_MIN=1 (tools/devbuild.sh): a library with the kernels of ONE regime only -- opt_shape.py's two renderers and the team
 // kernels -- that compiles in seconds instead of minutes, for A/B experiments on those kernels.  Never shipped: every other option
-// set lands on a kernel of another option set.
+// set lands on a kernel of another option set.  -DGENDR_DEV_MIN=2: BASELINE config 2's kernels only (tools/ab.sh on compiler flags).
 #ifndef GENDR_DEV_MIN
 #define GENDR_DEV_MIN 0
 #endif
-#if GENDR_DEV_MIN
+#if GENDR_DEV_MIN == 2
+const KernelEntry kSpecialised[] = {
+    GENDR_SPECIALISE_K(kUniform,     kProbabilistic, 1, 0, kTexSurface1, w6, C2B),
+};
+#elif GENDR_DEV_MIN
 const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 0, 0, kTexSurface1),
     GENDR_SPECIALISE(kHeaviside,     kAlphaHard,     0, 0, kTexSurface1),

@@ -10,7 +10,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
+import ctypes
 import criteria, parity, scenes
+from gendr_amd import _native
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -19,6 +21,7 @@ with_ref = 'ref' in sys.argv[3:] and parity.reference_available() and parity.ref
 small_rs = np.random.RandomState(77)           # (its own stream: the draw of everything else stays the plain campaign's)
 names = [n for n, _ in scenes.OPTION_MATRIX]
 bad = 0
+n_team = 0
 for case in range(n_cases):
     name, opts = scenes.OPTION_MATRIX[rs.randint(len(names))]
     opts = dict(opts)
@@ -47,6 +50,18 @@ for case in range(n_cases):
     same = all(np.array_equal(h[k], h2[k], equal_nan=True) for k in ('rgba', 'aggrs_info'))
     if not same:
         fails.append('culled != all-pairs')
+    # team kernels (round 5; chosen automatically for calls of few tiles where the option set has one): the forward results must be
+    # bit for bit those of the one-wave kernels (team = -1 switches them off), the gradients differ by the order of the atomics only
+    h3 = parity.run_hip(fv, tex, isz, dict(opts, team=-1), grad)
+    o_, extra_ = parity.split_options(opts)
+    on_team = bool(_native.lib().gendr_uses_team(B, nf, T, ctypes.byref(parity.hip_params(isz, o_, extra_)), 0))
+    n_team += on_team
+    if not all(np.array_equal(h[k], h3[k], equal_nan=True) for k in ('rgba', 'aggrs_info')):
+        fails.append('team != one-wave kernels (forward)')
+    for k in ('grad_faces', 'grad_textures'):
+        den = max(float(np.nanmax(np.abs(h3[k]))), 1e-30)
+        if not float(np.nanmax(np.abs(h[k].astype(np.float64) - h3[k]))) <= 2e-5 * den:
+            fails.append('team != one-wave kernels (%s, %.1e of the largest element)' % (k, float(np.nanmax(np.abs(h[k].astype(np.float64) - h3[k]))) / den))
     if with_ref and parity.split_options(opts)[1]['texel_mode'] == 0:        # (the reference has no clamped texel mode)
         r1 = parity.run_reference(fv, tex, isz, opts, grad, np.float32)
         r2 = parity.run_reference(fv, tex, isz, opts, grad, np.float32, variant='render_fma')
@@ -59,6 +74,6 @@ for case in range(n_cases):
                          % (int(viol.sum()), int(agree.sum()), tuple(int(v) for v in np.argwhere(viol)[0])))
     status = 'ok' if not fails else 'FAIL ' + '; '.join(fails)
     bad += bool(fails)
-    print('%3d %-24s B=%d nf=%3d is=%3d T=%d scale=%.2f  rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, res['rgba']['max_rel'], status), flush=True)
-print('%d / %d cases failed' % (bad, n_cases))
+    print('%3d %-24s B=%d nf=%3d is=%3d T=%d scale=%.2f %s rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, 'team' if on_team else '    ', res['rgba']['max_rel'], status), flush=True)
+print('%d / %d cases failed (%d of them rendered by the team kernels)' % (bad, n_cases, n_team))
 sys.exit(1 if bad else 0)
