@@ -70,7 +70,7 @@ EXPORTS = (
     "gendr_cull_radius", "gendr_project_faces", "gendr_project_faces_backward",
     "gendr_camera_rotation", "gendr_camera_rotation_backward",
     "gendr_silhouette_workspace_bytes", "gendr_silhouette_forward", "gendr_silhouette_backward", "gendr_workspace_bytes_f64", "gendr_forward_f64", "gendr_backward_f64", "gendr_selftest", "gendr_light_faces", "gendr_light_faces_backward", "gendr_voxelize_workspace_bytes", "gendr_voxelize", "gendr_load_textures", "gendr_create_texture_image",
-    "gendr_uses_team",
+    "gendr_uses_team", "gendr_uses_team_cover",
 )
 
 _libs = {}
@@ -179,6 +179,8 @@ def lib(variant=None):
     L.gendr_project_faces_backward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
     L.gendr_uses_team.restype = i
     L.gendr_uses_team.argtypes = [i, i, i, pp, i]
+    L.gendr_uses_team_cover.restype = i
+    L.gendr_uses_team_cover.argtypes = [i, i, i, pp]
     L.gendr_cull_radius.restype = f
     L.gendr_cull_radius.argtypes = [pp]
     L.gendr_params_size.restype = i

@@ -204,6 +204,27 @@ const TeamEntry* pick_team(const gendr_params* p, int texm, bool silhouette, lon
     return (r < 1e18f && r * (float)p->image_size * 0.5f >= kTeamMinRadiusPx) ? t : nullptr;
 }
 
+// The coverage kernel's team form (cover_kernel<REC, 8>: one 8-wave workgroup per listed tile, wave w examines faces [16 w, 16 w + 16)
+// of every 128 the tile lists; the same entries in the same slots).  It pays where a tile lists faces by the dozen AND the call holds
+// too few tiles to fill the chip with one wave each -- independent of whether the option set has team RENDER kernels (the heavy
+// distributions at opt_shape.py's shape have none and still list 200 faces per tile).  Measured (tools/tcover_sweep.sh, forward phase,
+// one-wave -> team form, logistic with sigma 1e-4 ... 3e-2): 64^2 x 24 0.053 -> 0.048 ... 0.521 -> 0.473 ms (the coverage kernel itself at
+// opt_shape.py's shape 30.8 -> 20.3 us, at 70^2 x 5 with sigma 3e-2 89 -> 29 us), 64^2 x 8 0.044 -> 0.038 ... 0.320 -> 0.260; 128^2 x 8 and
+// 256^2 x 1 level up to sigma 3e-3, then 0.131 -> 0.126 / 0.130 -> 0.122 and 0.561 -> 0.518 / 0.447 -> 0.407; 256^2 x 4 with short lists
+// 0.046 -> 0.049: hence a rule on the faces a tile can expect to list -- nf x ((tile + 2 radii) / image + the width of a face of
+// 2 / nf of the image)^2 >= 32, two steps' worth -- for calls of up to kTeamMaxTiles tiles.  gendr_params::team: -1 never, 2 always.
+constexpr float kTeamCoverMinFaces = 32.f;
+bool team_cover(const gendr_params* p, int nf, long total_tiles, long ent_cap8)
+{
+    if (p->team < 0 || !p->cull || ent_cap8 <= 0) return false;
+    if (p->team >= 2) return true;
+    if (total_tiles > kTeamMaxTiles) return false;
+    const float r = gendr_cull_radius(p);
+    if (!(r < 1e18f)) return false;
+    const float span = ((float)kTile + r * (float)p->image_size) / (float)p->image_size + sqrtf(2.f / (float)std::max(nf, 1));
+    return (float)nf * span * span >= kTeamCoverMinFaces;
+}
+
 struct Workspace {
     size_t boxes_off, records_off, masks_off, lists_off, tileinfo_off, entries_off, hints_off, sorted_off, loose_off, control_off, det_off, total;
     bool ordered;              // the render kernels walk the heavy-first copy of the queue records (order_tiles_kernel)
@@ -510,6 +531,13 @@ int gendr_uses_team(int B, int nf, int T, const gendr_params* p, int silhouette)
     if (gendr_validate(p, B, nf, T) != GENDR_OK || B == 0) return 0;
     const Workspace w = workspace_layout(B, nf, T, p);
     return pick_team(p, texture_mode(p, T), silhouette != 0, (long)B * w.tiles_x * w.tiles_x, w.ent_cap8) ? 1 : 0;
+}
+
+int gendr_uses_team_cover(int B, int nf, int T, const gendr_params* p)
+{
+    if (gendr_validate(p, B, nf, T) != GENDR_OK || B == 0) return 0;
+    const Workspace w = workspace_layout(B, nf, T, p);
+    return team_cover(p, nf, (long)B * w.tiles_x * w.tiles_x, w.ent_cap8) ? 1 : 0;
 }
 
 float gendr_sigmoid_forward(int function_id, float sign, float x, float scale, float dist_shape, float dist_shift)
@@ -859,10 +887,19 @@ static int face_setup_impl(const float* faces, const float* textures, void* work
         const bool dense = k.key.dist < 0 || k.key.dist == kLogistic || (GENDR_DENSE_GAMMA && k.key.dist == kGamma);           // dense_path<DIST>() of gendr_kernels.h
         a.want_tags = (dense && cull_r * (float)p->image_size * 0.5f >= (float)kTile) ? 1 : 0;
     }
-    const int cblocks = render_blocks(a.total_blocks) * GENDR_COVER_GRID_MUL;
-    if (texm == kTexSurface1)    hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurface1)>, dim3(cblocks), dim3(kThreads), 0, s, a);
-    else if (texm == kTexVertex) hipLaunchKernelGGL(cover_kernel<record_floats(kTexVertex)>, dim3(cblocks), dim3(kThreads), 0, s, a);
-    else                         hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurfaceN)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+    if (team_cover(p, nf, a.total_tiles, a.ent_cap8)) {
+        // one 8-wave workgroup per listed tile, at most twice what the chip holds of them per queue
+        const int per_queue = (int)((a.total_tiles + 7) / 8);
+        const int tblocks = 8 * std::max(1, std::min(per_queue, 256));
+        if (texm == kTexSurface1)    hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurface1), 8>), dim3(tblocks), dim3(kThreads * 8), 0, s, a);
+        else if (texm == kTexVertex) hipLaunchKernelGGL((cover_kernel<record_floats(kTexVertex), 8>), dim3(tblocks), dim3(kThreads * 8), 0, s, a);
+        else                         hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurfaceN), 8>), dim3(tblocks), dim3(kThreads * 8), 0, s, a);
+    } else {
+        const int cblocks = render_blocks(a.total_blocks) * GENDR_COVER_GRID_MUL;
+        if (texm == kTexSurface1)    hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurface1)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+        else if (texm == kTexVertex) hipLaunchKernelGGL(cover_kernel<record_floats(kTexVertex)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+        else                         hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurfaceN)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+    }
     e = check_launch();
     if (e != GENDR_OK) return e;
     // heavy tiles first: the render kernels walk the sorted copy of the queue records

@@ -1373,13 +1373,23 @@ __device__ __forceinline__ unsigned quad_or(unsigned v)
     return v;
 }
 
-template <int REC>
-__global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
+template <int REC, int WAVES = 1>
+__global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArgs a)
 {
+    // WAVES == 8 (team calls, gendr_params::team: few tiles, each listing faces by the hundred -- opt_shape.py's 64^2 images with
+    // a 4-pixel logistic tail list 200 faces per tile, and one wave per tile walks them in thirteen dependent steps on a chip
+    // that holds 1.5 such waves per SIMD): one WORKGROUP per tile.  Every wave unpacks the same kListCap = 8 x 16 faces of a
+    // round (only wave 0 stores the list), wave w examines faces [16 w, 16 w + 16) of it, and the survivors are appended in face
+    // order through the waves' counts in LDS -- the same entries in the same slots as the one-wave form.
+    static_assert(WAVES == 1 || 16 * WAVES == kListCap, "a round of the team form is one step per wave");
     __shared__ int s_flist[kListCap];
+    __shared__ int s_cnt[WAVES > 1 ? WAVES : 1];
+    __shared__ int s_pairs;
     GENDR_SPAN_BEGIN;
     TileWalk tw;
     walk_init(tw, a, 1);
+    const int wave = WAVES > 1 ? (int)(threadIdx.x >> 6) : 0;
+    if (WAVES > 1) tw.rank = tw.next = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3));      // one work item per workgroup
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // sixteen faces per step: the four lanes of a quad share a face, lane q of the quad tests pixel rows q and q + 4 of the tile
@@ -1427,14 +1437,17 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 const int cnt = __popcll(w);
                 if (nlist + cnt > kListCap) break;                       // the word stays in nz for the next round
                 nz &= nz - 1;
-                if ((w >> lane) & 1ull) s_flist[nlist + __popcll(w & lt)] = (group0 + j) * 64 + lane;
+                if (wave == 0 && ((w >> lane) & 1ull)) s_flist[nlist + __popcll(w & lt)] = (group0 + j) * 64 + lane;
                 nlist += cnt;
             }
-            __builtin_amdgcn_wave_barrier();
+            if (WAVES > 1) { if (threadIdx.x == 0) s_pairs = 0; __syncthreads(); } else __builtin_amdgcn_wave_barrier();
             // ---- sixteen faces per step (round 4: eight, one row per lane -- a wave of this kernel waits for the dependent loads of
             // each step, face list -> record, far longer than it computes: half the steps, and the per-edge terms that do not
             // depend on the row are shared by the lane's two rows)
-            for (int i0 = 0; i0 < nlist; i0 += 16) {
+            CoverEnt my_ent; my_ent.fn = 0; my_ent.npix = 0; my_ent.lo = 0u; my_ent.hi = 0u;      // team form: this wave's entry of the round, stored after the counts are known
+            bool my_owns = false;
+            unsigned long long my_keep = 0ull;
+            for (int i0 = 16 * wave; i0 < nlist; i0 += 16 * WAVES) {
                 const bool has = i0 + slot < nlist;
                 const int fn = s_flist[has ? i0 + slot : i0];
                 float r[kRecStage1];
@@ -1561,14 +1574,24 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
                 }
                 const bool owns = prow == 0 && (v | hi) != 0u;
                 const unsigned long long keep = __ballot(owns);
-                if (owns) {
-                    CoverEnt e;
-                    e.fn = fn; e.npix = (__popc(v) + __popc(hi)) | (tag << 8); e.lo = v; e.hi = hi;
-                    out[nout + __popcll(keep & lt)] = e;
+                CoverEnt e;
+                e.fn = fn; e.npix = (__popc(v) + __popc(hi)) | (tag << 8); e.lo = v; e.hi = hi;
+                if (WAVES > 1) { my_ent = e; my_owns = owns; my_keep = keep; }
+                else {
+                    if (owns) out[nout + __popcll(keep & lt)] = e;
+                    nout += __popcll(keep);
                 }
-                nout += __popcll(keep);
             }
-            __builtin_amdgcn_wave_barrier();
+            if (WAVES > 1) {
+                if (lane == 0) s_cnt[wave] = __popcll(my_keep);
+                __syncthreads();
+                int before = 0, all = 0;
+#pragma unroll
+                for (int k = 0; k < WAVES; k++) { const int c = s_cnt[k]; all += c; if (k < wave) before += c; }
+                if (my_owns) out[nout + before + __popcll(my_keep & lt)] = my_ent;
+                nout += all;
+                __syncthreads();                       // s_flist and s_cnt are rewritten by the next round
+            } else __builtin_amdgcn_wave_barrier();
         }
         // the tile's (pixel, face) pairs = its weight for order_tiles_kernel: summed across the lanes into lane 63 (an
         // inclusive scan inside each row of 16 lanes, then the two DPP row broadcasts: six VALU steps, no LDS)
@@ -1580,7 +1603,12 @@ __global__ __launch_bounds__(kThreads) void cover_kernel(const RenderArgs a)
         my_pairs = GENDR_DPP_IADD(my_pairs, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
         my_pairs = GENDR_DPP_IADD(my_pairs, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
 #undef GENDR_DPP_IADD
-        if (lane == 63) a.tile_info_raw[tw.qbase + slot_c] = make_int4(tile, off, nout, my_pairs);
+        if (WAVES > 1) {
+            if (lane == 63) atomicAdd(&s_pairs, my_pairs);
+            __syncthreads();
+            if (threadIdx.x == 63) a.tile_info_raw[tw.qbase + slot_c] = make_int4(tile, off, nout, s_pairs);
+            __syncthreads();                           // s_pairs is cleared by the next tile's first round
+        } else if (lane == 63) a.tile_info_raw[tw.qbase + slot_c] = make_int4(tile, off, nout, my_pairs);
     }
     GENDR_SPAN_END(0, blockIdx.x);
 }

@@ -114,7 +114,11 @@ typedef struct gendr_params {
                                       (logistic / probabilistic, surface texture with T = 1, and its alpha-only twin) when the
                                       call holds at most 4096 tiles (8192 with a cull radius of 2 pixels and more); 1: on wherever a
                                       team kernel exists; -1: off.  gendr_forward and gendr_backward must be called with the
-                                      same setting (the pair hints depend on it); ignored with `deterministic`. */
+                                      same setting (the pair hints depend on it); ignored with `deterministic`.
+                                      The COVERAGE kernel has a team form of its own (one 8-wave workgroup per listed tile, the same
+                                      entries in the same slots), chosen for calls of up to 8192 tiles whose tiles can expect to
+                                      list 32 faces and more, whatever the option set: -1 switches it off as well, 2 = 1 with that
+                                      form at every shape (tests). */
 } gendr_params;
 
 /* Bytes of the caller-owned workspace that gendr_face_setup / gendr_forward fill and gendr_backward
@@ -131,6 +135,8 @@ int gendr_validate(const gendr_params* p, int B, int nf, int T);
 /* 1 if gendr_forward / gendr_backward (silhouette != 0: gendr_silhouette_forward / _backward) render this call with the team
  * kernels (gendr_params::team), else 0.  A host-side decision on the shapes and the option set only; for tests and reports. */
 int gendr_uses_team(int B, int nf, int T, const gendr_params* p, int silhouette);
+/* 1 if the coverage kernel of this call (gendr_face_setup, gendr_forward, gendr_silhouette_forward) runs in its team form. */
+int gendr_uses_team_cover(int B, int nf, int T, const gendr_params* p);
 
 /* Per-face preprocessing into this build's record layout (replaces forward_render_inv_cuda_kernel,
  * kernel.cu:620-676, launched at :1100-1109) followed by the tile binning of the exact culling.
