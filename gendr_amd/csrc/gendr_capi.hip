@@ -213,12 +213,16 @@ const TeamEntry* pick_team(const gendr_params* p, int texm, bool silhouette, lon
 // 256^2 x 1 level up to sigma 3e-3, then 0.131 -> 0.126 / 0.130 -> 0.122 and 0.561 -> 0.518 / 0.447 -> 0.407; 256^2 x 4 with short lists
 // 0.046 -> 0.049: hence a rule on the faces a tile can expect to list -- nf x ((tile + 2 radii) / image + the width of a face of
 // 2 / nf of the image)^2 >= 32, two steps' worth -- for calls of up to kTeamMaxTiles tiles.  gendr_params::team: -1 never, 2 always.
+#ifndef GENDR_TEAM_COVER_MAX_TILES
+#define GENDR_TEAM_COVER_MAX_TILES 8192
+#endif
 constexpr float kTeamCoverMinFaces = 32.f;
+constexpr long kTeamCoverMaxTiles = GENDR_TEAM_COVER_MAX_TILES;
 bool team_cover(const gendr_params* p, int nf, long total_tiles, long ent_cap8)
 {
     if (p->team < 0 || !p->cull || ent_cap8 <= 0) return false;
     if (p->team >= 2) return true;
-    if (total_tiles > kTeamMaxTiles) return false;
+    if (total_tiles > kTeamCoverMaxTiles) return false;
     const float r = gendr_cull_radius(p);
     if (!(r < 1e18f)) return false;
     const float span = ((float)kTile + r * (float)p->image_size) / (float)p->image_size + sqrtf(2.f / (float)std::max(nf, 1));
