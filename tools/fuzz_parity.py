@@ -22,6 +22,7 @@ small_rs = np.random.RandomState(77)           # (its own stream: the draw of ev
 names = [n for n, _ in scenes.OPTION_MATRIX]
 bad = 0
 n_team = 0
+n_tcover = 0
 for case in range(n_cases):
     name, opts = scenes.OPTION_MATRIX[rs.randint(len(names))]
     opts = dict(opts)
@@ -56,6 +57,8 @@ for case in range(n_cases):
     o_, extra_ = parity.split_options(opts)
     on_team = bool(_native.lib().gendr_uses_team(B, nf, T, ctypes.byref(parity.hip_params(isz, o_, extra_)), 0))
     n_team += on_team
+    on_tcover = bool(_native.lib().gendr_uses_team_cover(B, nf, T, ctypes.byref(parity.hip_params(isz, o_, extra_))))
+    n_tcover += on_tcover
     if not all(np.array_equal(h[k], h3[k], equal_nan=True) for k in ('rgba', 'aggrs_info')):
         fails.append('team != one-wave kernels (forward)')
     for k in ('grad_faces', 'grad_textures'):
@@ -74,6 +77,6 @@ for case in range(n_cases):
                          % (int(viol.sum()), int(agree.sum()), tuple(int(v) for v in np.argwhere(viol)[0])))
     status = 'ok' if not fails else 'FAIL ' + '; '.join(fails)
     bad += bool(fails)
-    print('%3d %-24s B=%d nf=%3d is=%3d T=%d scale=%.2f %s rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, 'team' if on_team else '    ', res['rgba']['max_rel'], status), flush=True)
-print('%d / %d cases failed (%d of them rendered by the team kernels)' % (bad, n_cases, n_team))
+    print('%3d %-24s B=%d nf=%3d is=%3d T=%d scale=%.2f %s rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, ('team' if on_team else '    ') + ('+tc' if on_tcover else '   '), res['rgba']['max_rel'], status), flush=True)
+print('%d / %d cases failed (%d draws rendered by the team kernels, %d with the coverage kernel in its team form)' % (bad, n_cases, n_team, n_tcover))
 sys.exit(1 if bad else 0)
