@@ -449,13 +449,17 @@ int resident_per_queue(render_kernel_t k, int threads = kThreads)
 }
 
 // Work items (tile pieces) per queue the graded sub-tile split may create (order_tiles_kernel): what the chip holds of the
-// render kernel with the smaller occupancy at once, plus a quarter (the pieces are uneven).  Both render kernels walk the same
-// grades (the pair hints depend on it), and both are launched with at least that many waves per queue.
+// render kernel with the smaller occupancy at once -- and not one more.  (Rounds 4-5 added a quarter "because the pieces are
+// uneven"; the wave time line of the backward kernel at 8 frames -- tools/wave_trace.py -- then showed what the surplus does: work
+// items beyond the resident waves start when a slot frees, 14 us into a 32-us launch, and the launch ends with them.  Measured,
+// forward + backward call in ms, budget x 1.25 -> x 1: batch 1 0.074 -> 0.069, 2 0.079 -> 0.076, 4 0.083 -> 0.078, 8 0.100 -> 0.096,
+// 16 0.116 -> 0.109, from 32 unchanged; x 0.875: batch 8 0.094 but batch 16 0.117; x 1.5: slower everywhere -- tools/ab_batches.sh.)
+// Both render kernels walk the same grades (the pair hints depend on it), and both are launched with at least that many waves per queue.
 int split_budget(const gendr_params* p, int texm, bool silhouette)
 {
     const KernelEntry& k = pick_kernel(p, texm, silhouette);
     const int r = std::min(resident_per_queue(k.fwd), resident_per_queue(k.bwd));
-    return r + (r >> 2);
+    return r;
 }
 
 // Grid of a team kernel: the workgroups the chip holds at once (a team keeps its tile's state in LDS: a second generation of
