@@ -2,7 +2,8 @@
 suite touches these calls on a GPU): the RCCL process group of one rank (GENDR_BENCH_FORCE_DIST=1: init with device_id, barrier,
 all-reduce of the elapsed time, BASELINE config 4's all-gather / reduce-scatter of views over backend nccl), and the driver's own
 launch line -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` -- with both ranks on this GPU over gloo
-(GENDR_BENCH_OVERSUBSCRIBE=1: RCCL refuses two ranks on one device)."""
+(GENDR_BENCH_OVERSUBSCRIBE=1: RCCL refuses two ranks on one device).
+(File name: last in the suite's order -- the driver runs `pytest -x`, and a launcher problem of the box must not hide the parity tests.)"""
 import json
 import os
 import socket
