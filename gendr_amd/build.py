@@ -100,7 +100,6 @@ def build_torch_ext(force=False, verbose=False):
     import sysconfig
     import torch
     from torch.utils import cpp_extension as ce
-    import pybind11
     import fcntl
     tl = os.path.join(os.path.dirname(torch.__file__), "lib")
     cxx = shutil.which("g++") or "g++"
@@ -112,7 +111,7 @@ def build_torch_ext(force=False, verbose=False):
                 cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
                        "-DTORCH_EXTENSION_NAME=_gendr_torch", "-DTORCH_API_INCLUDE_EXTENSION_H",
                        "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
-                cmd += ["-I" + d for d in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(), "-I/opt/rocm/include"]
+                cmd += ["-I" + d for d in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include"]   # (torch ships the pybind11 headers it was built with)
                 cmd += [TORCH_EXT_SRC, "-o", tmp, "-L" + tl, "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python",
                         "-Wl,-rpath," + tl]
                 if verbose:

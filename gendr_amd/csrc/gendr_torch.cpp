@@ -108,6 +108,10 @@ struct GenDRNode : public torch::autograd::Function<GenDRNode> {
         const std::string pb = ctx->saved_data["params"].toStringRef();
         std::memcpy(&p, pb.data(), sizeof(p));
         const int64_t B = faces.size(0), nf = faces.size(1), T = tex.size(2);
+        // like GenDRFunction (@once_differentiable): the gradients returned here carry no graph, so a double backward
+        // (create_graph=True) must fail loudly instead of treating them as constants
+        TORCH_CHECK(!(at::GradMode::is_enabled() && grad_out[0].defined() && grad_out[0].requires_grad()),
+                    "gendr render: the backward pass is hand-derived and not differentiable a second time (create_graph=True is not supported)");
         torch::Tensor grad = grad_out[0].to(faces.device(), torch::kFloat32).contiguous();
         const int64_t n_f = B * nf * 9, n_t = tex.numel(), n_f_pad = (n_f + 63) / 64 * 64;
         torch::Tensor flat;

@@ -121,14 +121,30 @@ _ENV_KEYS = ('GENDR_TEXEL_MODE', 'GENDR_CULL', 'GENDR_DETERMINISTIC', 'GENDR_POO
              'GENDR_SKIP_UNLISTED_AUX', 'GENDR_FUSED_CLEAR')
 
 
+def _key_scalar(v):
+    """An option value as the plain Python scalar make_params() would make of it.  Tensors (0-d, nn.Parameter) and numpy
+    arrays hash by IDENTITY, so keyed on the object an in-place update (sigma.mul_(0.9), optimizer.step()) would keep
+    hitting the entry of the old value; their value is read here, which costs one .item() -- no cache would cost
+    the whole normalisation."""
+    if isinstance(v, bool):
+        return ('bool', v)                              # True == 1 as a key, but make_params() rejects a bool where an id is expected
+    if v is None or isinstance(v, (str, int, float)):
+        return v
+    try:
+        return float(v)                                 # numpy scalars, 0-d tensors / arrays: what the reference's __float__ does
+    except (TypeError, ValueError):
+        raise TypeError('unhashable option')
+
+
 def _params_bytes(image_size, background_color, *options):
     """(gendr_params as bytes, fused gradient clear?) for the C++ node; cached per option set and environment -- an optimisation loop
-    renders with the same options thousands of times, and normalising them costs the host more than the launch."""
+    renders with the same options thousands of times, and normalising them costs the host more than the launch.  The key is built
+    from the options' VALUES (see _key_scalar), never from the objects."""
     env = tuple(os.environ.get(k) for k in _ENV_KEYS)
     try:
-        key = (image_size, tuple(background_color), options, env)
+        key = (_key_scalar(image_size), tuple(_key_scalar(c) for c in background_color), tuple(_key_scalar(o) for o in options), env)
         hit = _PARAMS_CACHE.get(key)
-    except TypeError:                                   # an unhashable option (a tensor-valued scalar, ...): no caching
+    except TypeError:                                   # an option no scalar can be made of: no caching, make_params() reports it
         key, hit = None, None
     if hit is None:
         p = make_params(image_size, background_color, *options)

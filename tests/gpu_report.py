@@ -94,6 +94,17 @@ def one_case(fv, tex, isz, opts, with_cull_check=True, n_jitter=len(criteria.JIT
                                  elementwise_bracket={k: dict(violations=b['violations'], n=b['n'], worst_over_bound=b['worst_over_bound']) for k, b in br.items()})
         entry['reference_kernels']['flat_1e5'] = {v: dict(meets=not pin.exceptions_of(m), max={k: x['max'] for k, x in m.items()},
                                                           frac_gt_1e5={k: x['frac'] for k, x in m.items()}) for v, m in flat.items()}
+        # the PLAIN relative error SURVEY 8(d) names -- |got - ref| / max(|ref|, 1e-6 max|ref|), no conditioning --
+        # of both gradients against the reference kernels' float output, next to the conditioned one the gate uses (pin.measure:
+        # relative to max(|ref|, sum of |contributions|)): the two differ only on elements that are the small difference of
+        # large contributions, whose float value depends on the summation order (atomics) in the reference as well -- the
+        # reference's own two builds are given the same treatment for scale
+        def _plain(a):
+            return {k: {q: parity.stats(a[k], np.asarray(r32[k]).reshape(np.asarray(a[k]).shape))[q] for q in ('max_rel', 'p99_rel', 'frac_gt_1e5')}
+                    for k in ('grad_faces', 'grad_textures') if np.asarray(r32[k]).size}
+        entry['reference_kernels']['plain_relative'] = dict({v: _plain(hips[v]) for v in hips}, reference_fma_build=_plain(rf))
+        entry['reference_kernels']['conditioned_relative'] = {v: {k: {q: m[k][q] for q in ('max', 'p99', 'frac')} for k in ('grad_faces', 'grad_textures') if k in m}
+                                                              for v, m in flat.items()}
         entry['reference_kernels']['reference_fma_vs_nofma'] = {k: {q: x[q] for q in ('max', 'p50', 'p99', 'p999', 'frac')} for k, x in spread.items()}
     if with_cull_check:
         h, h2 = hips['default'], parity.run_hip(fv, tex, isz, dict(opts, cull=0), grad)
@@ -121,7 +132,7 @@ def short(name, entry):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
     try:
         head = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
@@ -174,6 +185,9 @@ def main():
             restatement_f64_grad_faces_max_without_cauchy=max(r['restatement_vs_reference_f64']['grad_faces_max'] for r in non_cauchy))
         summ['reference_kernels']['flat_1e5_met'] = {v: sum(1 for r in pinned if r['flat_1e5'].get(v, {}).get('meets')) for v in ('default', 'exact', 'fast')
                                                      if any(v in r['flat_1e5'] for r in pinned)}
+        summ['reference_kernels']['gradients_at_baseline_configs'] = {
+            name: dict(plain=c['reference_kernels']['plain_relative'], conditioned=c['reference_kernels']['conditioned_relative'])
+            for name, c in out['full_size'].items() if 'reference_kernels' in c}
         fast = [c['fast'] for c in cases if 'fast' in c]
         if fast:
             summ['fast_variant'] = dict(
@@ -194,6 +208,7 @@ def main():
             return [compact(v) for v in x]
         return x
     json.dump(compact(out), open(path, 'w'), separators=(',', ':'))
+    print('ref_pin: ran %d cases against the reference kernels (oracle/_ref)' % len(pinned))
     print('wrote', path, json.dumps(out['summary']))
 
 

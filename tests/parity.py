@@ -102,6 +102,8 @@ def run_reference(fv, tex, image_size, opts, grad=None, dtype=np.float32, varian
     launched by oracle/ref_gpu.py).  Same inputs / outputs as run_oracle.  texel_mode has no meaning here (the reference
     has one behaviour, the one texel_mode = 0 restates)."""
     from oracle import ref_gpu
+    global REF_PIN_CALLS
+    REF_PIN_CALLS += 1
     o, extra = split_options(opts)
     assert extra['texel_mode'] == 0, 'the reference has no clamped texel mode'
     p = hip_params(image_size, o, extra)
@@ -119,6 +121,7 @@ def run_reference(fv, tex, image_size, opts, grad=None, dtype=np.float32, varian
 
 
 GRAD_FLOOR = 1e-6
+REF_PIN_CALLS = 0      # launches of the reference's own kernels in this process: tests/conftest.py prints it, so a silently skipped pin shows
 
 
 def rel_error(got, ref, scale=None, floor=1e-10):

@@ -98,3 +98,38 @@ OPTION_MATRIX = [
     ("uniform_T9_clamp", dict(T=9, texel_mode=1)),
     ("uniform_T1_clamp", dict(texel_mode=1)),
 ]
+
+
+# every dist_func / aggr_alpha_func id with parameters that are valid by gendr_validate's rules (kernel.cu:296,491,501,512,522,534,552):
+# the axes of tests/test_gpu_cross_product.py and of the fuzz draws' independent picks
+DISTS = [
+    ('hard', {}), ('uniform', dict(dist_scale=2e-2)), ('cubic_hermite', dict(dist_scale=5e-2)),
+    ('wigner_semicircle', dict(dist_scale=5e-2)), ('gaussian', dict(dist_scale=2e-2)), ('laplace', dict(dist_scale=2e-2)),
+    ('logistic', dict(dist_scale=2e-2)), ('gudermannian', dict(dist_scale=2e-2)), ('cauchy', dict(dist_scale=1e-2)),
+    ('reciprocal', dict(dist_scale=1e-2)), ('gumbel_max', dict(dist_scale=2e-2)), ('gumbel_min', dict(dist_scale=2e-2)),
+    ('exponential', dict(dist_scale=3e-2, dist_shift=0.5)), ('exponential_rev', dict(dist_scale=2e-2)),
+    ('gamma', dict(dist_scale=2e-2, dist_shape=2.0)), ('gamma_rev', dict(dist_scale=2e-2, dist_shape=1.5)),
+    ('levy', dict(dist_scale=2e-2, dist_shift=1.0)), ('levy_rev', dict(dist_scale=1e-2)),
+]
+AGGRS = [
+    ('hard', None), ('max', None), ('probabilistic', None), ('einstein', None), ('hamacher', 0.5), ('frank', 3.0),
+    ('yager', 2.0), ('aczel_alsina', 0.7), ('dombi', 1.5), ('schweizer_sklar', -1.5),
+]
+
+
+def independent_options(rs, opts):
+    """The fuzz draws used to pick one of OPTION_MATRIX's 31 named option sets (dist and aggr never varied
+    independently).  Half of the draws now replace the set's t-conorm, half its distribution, by an independent pick."""
+    opts = dict(opts)
+    if rs.randint(2):
+        a, p = AGGRS[rs.randint(len(AGGRS))]
+        opts['aggr_alpha_func'] = a
+        opts.pop('aggr_alpha_t_conorm_p', None)
+        if p is not None:
+            opts['aggr_alpha_t_conorm_p'] = p
+    if rs.randint(2):
+        d, dopt = DISTS[rs.randint(len(DISTS))]
+        for k in ('dist_scale', 'dist_shape', 'dist_shift', 'dist_squared'):
+            opts.pop(k, None)
+        opts.update(dopt, dist_func=d)
+    return opts

@@ -313,3 +313,35 @@ def test_cpp_autograd_node_equals_the_python_function(native_lib):
     with torch.no_grad():
         b = R.render(fv.reshape(3, 40, 9), tex, image_size=48, dist_func='logistic', dist_scale=2e-2, background_color=[0.1, 0.2, 0.3])
     assert torch.equal(b, out[True][0])
+
+
+def test_tensor_valued_options_are_read_by_value_on_every_call(native_lib):
+    """a 0-d tensor / nn.Parameter passed as dist_scale and updated IN PLACE between two render() calls (sigma.mul_(),
+    optimizer.step()) must render with the new value -- the option cache of the C++ node's path is keyed on values, not objects."""
+    from gendr_amd.functional import renderer as R
+    fv, tex = _inputs(B=2, nf=24)
+    sigma = torch.nn.Parameter(torch.tensor(1e-2))
+    a = R.render(fv, tex, image_size=40, dist_scale=sigma)
+    with torch.no_grad():
+        sigma.mul_(10)
+    b = R.render(fv, tex, image_size=40, dist_scale=sigma)
+    assert torch.equal(b, R.render(fv, tex, image_size=40, dist_scale=float(sigma)))
+    assert not torch.equal(a, b)
+    g = np.float64(3e-3)
+    assert torch.equal(R.render(fv, tex, image_size=40, aggr_rgb_gamma=g), R.render(fv, tex, image_size=40, aggr_rgb_gamma=float(g)))
+
+
+def test_double_backward_raises_on_both_paths(native_lib):
+    """GenDRFunction is @once_differentiable; the C++ node must refuse create_graph=True as loudly."""
+    from gendr_amd.functional import renderer as R
+    fv, tex = _inputs(B=1, nf=16)
+    for mode in (True, False):
+        R._CPP_AUTOGRAD = mode
+        try:
+            a = fv.clone().requires_grad_(True)
+            img = R.render(a, tex, image_size=32)
+            with pytest.raises(RuntimeError):
+                (ga,) = torch.autograd.grad(img.sum(), a, create_graph=True)
+                ga.sum().backward()
+        finally:
+            R._CPP_AUTOGRAD = True

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def _draw(rs):
     name, opts = scenes.OPTION_MATRIX[rs.randint(len(scenes.OPTION_MATRIX))]
-    opts = dict(opts)
+    opts = scenes.independent_options(rs, opts)              # dist_func and aggr_alpha_func picked independently
+    name = '%s>%s/%s' % (name, opts.get('dist_func', 'uniform'), opts.get('aggr_alpha_func', 'probabilistic'))
     B = int(rs.choice([1, 2, 3, 5, 9]))
     nf = int(rs.choice([1, 2, 17, 63, 64, 65, 127, 130, 200]))
     isz = int(rs.choice([8, 13, 31, 64, 72, 100, 128, 136, 192, 200]))

@@ -211,3 +211,23 @@ def test_reference_code_object_manifest():
         for f, sha in man['reference_sha256'].items():
             assert sha == hashlib.sha256(open(os.path.join(build_ref.REF_CUDA_DIR, f), 'rb').read()).hexdigest()
     assert sorted(os.listdir(build_ref.REF_DIR)) == sorted(['manifest.json'] + [o['file'] for o in man['objects'].values()])
+
+
+def test_option_cache_is_keyed_on_values_not_objects():
+    """tensors hash by identity; an in-place update of a tensor-valued dist_scale must not hit the old entry."""
+    import numpy as np
+    import torch
+    from gendr_amd.functional import renderer as R
+    opts = lambda s, sq=False, df='uniform': (64, [0, 0, 0], df, s, sq, None, None, 1e4, 'probabilistic', None, 'softmax', 1e-3, 1e-3, 1, 100, True, 'surface')
+    s = torch.nn.Parameter(torch.tensor(1e-2))
+    a = R._params_bytes(*opts(s))[0]
+    with torch.no_grad():
+        s.mul_(10)
+    b = R._params_bytes(*opts(s))[0]
+    assert a != b
+    assert b == R._params_bytes(*opts(float(s)))[0]
+    assert R._params_bytes(*opts(np.float64(0.25)))[0] == R._params_bytes(*opts(0.25))[0]
+    assert R._params_bytes(*opts(0.25, sq=1))[0] == R._params_bytes(*opts(0.25, sq=True))[0]
+    R._params_bytes(*opts(0.25, df=1))
+    with pytest.raises(ValueError):                     # a cached id 1 must not let the bool True through (True == 1 as a dict key)
+        R._params_bytes(*opts(0.25, df=True))

@@ -25,7 +25,8 @@ n_team = 0
 n_tcover = 0
 for case in range(n_cases):
     name, opts = scenes.OPTION_MATRIX[rs.randint(len(names))]
-    opts = dict(opts)
+    opts = scenes.independent_options(rs, opts)              # dist_func and aggr_alpha_func picked independently
+    name = ('%s>%s/%s' % (name, opts.get('dist_func', 'uniform'), opts.get('aggr_alpha_func', 'probabilistic')))[:40]
     B = int(rs.choice([1, 2, 3, 5, 9]))
     nf = int(rs.choice([1, 2, 17, 63, 64, 65, 127, 130, 200]))
     isz = int(rs.choice([8, 13, 31, 64, 72, 100, 128, 136, 192, 200]))
@@ -77,6 +78,6 @@ for case in range(n_cases):
                          % (int(viol.sum()), int(agree.sum()), tuple(int(v) for v in np.argwhere(viol)[0])))
     status = 'ok' if not fails else 'FAIL ' + '; '.join(fails)
     bad += bool(fails)
-    print('%3d %-24s B=%d nf=%3d is=%3d T=%d scale=%.2f %s rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, ('team' if on_team else '    ') + ('+tc' if on_tcover else '   '), res['rgba']['max_rel'], status), flush=True)
+    print('%3d %-40s B=%d nf=%3d is=%3d T=%d scale=%.2f %s rgba max %.1e  %s' % (case, name, B, nf, isz, T, scale, ('team' if on_team else '    ') + ('+tc' if on_tcover else '   '), res['rgba']['max_rel'], status), flush=True)
 print('%d / %d cases failed (%d draws rendered by the team kernels, %d with the coverage kernel in its team form)' % (bad, n_cases, n_team, n_tcover))
 sys.exit(1 if bad else 0)
