@@ -62,13 +62,21 @@ struct KernelEntry { KernelKey key; render_kernel_t fwd, bwd; faces_kernel_t det
 #endif
 // -DGENDR_DEV_MIN=1 (tools/devbuild.sh): a library with the kernels of ONE regime only -- opt_shape.py's two renderers and the team
 // kernels -- that compiles in seconds instead of minutes, for A/B experiments on those kernels.  Never shipped: every other option
-// set lands on a kernel of another option set.  -DGENDR_DEV_MIN=2: BASELINE config 2's kernels only (tools/ab.sh on compiler flags).
+// set lands on a kernel of another option set.  -DGENDR_DEV_MIN=2 / 3 / 4: BASELINE config 2's / 3's / 4's kernels only (tools/ab.sh, tools/ab_cfg.sh).
 #ifndef GENDR_DEV_MIN
 #define GENDR_DEV_MIN 0
 #endif
 #if GENDR_DEV_MIN == 2
 const KernelEntry kSpecialised[] = {
     GENDR_SPECIALISE_K(kUniform,     kProbabilistic, 1, 0, kTexSurface1, w6, C2B),
+};
+#elif GENDR_DEV_MIN == 3      // BASELINE config 3's kernels only
+const KernelEntry kSpecialised[] = {
+    GENDR_SPECIALISE_K(kGaussian,    kEinstein,      1, 1, kTexSurface1, w6, wa),
+};
+#elif GENDR_DEV_MIN == 4      // BASELINE config 4's
+const KernelEntry kSpecialised[] = {
+    GENDR_SPECIALISE_OCC(kLogistic,  kProbabilistic, 1, 0, kTexSurface1),
 };
 #elif GENDR_DEV_MIN
 const KernelEntry kSpecialised[] = {
@@ -799,7 +807,7 @@ int gendr_span_read(unsigned long long* dst, int kernel, int n)
 int gendr_selftest(int what, unsigned long long* report16, void* stream)
 {
     if (!report16) return GENDR_E_NULL;
-    if (what < 0 || what > 4) return GENDR_E_SHAPE;
+    if (what < 0 || what > 6) return GENDR_E_SHAPE;
     if (hipMemsetAsync(report16, 0, 16 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return GENDR_E_LAUNCH;
     hipLaunchKernelGGL(selftest_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, what, report16);
     return check_launch();

@@ -107,7 +107,7 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 #define GENDR_PAIR_HINTS 1   // 0: no pair hints from the forward to the backward kernel (A/B builds)
 #endif
 #ifndef GENDR_ABLATE
-#define GENDR_ABLATE 0   // diagnostic builds only (tools/): 1..3 cut the forward loop short after a stage
+#define GENDR_ABLATE 0   // diagnostic builds only (tools/): 1, 2, 6, 7 cut the forward batch body short after a stage, 5 drops the fill (tools/fwd_phases.sh)
 #endif
 
 namespace gendr {
@@ -339,6 +339,29 @@ __device__ __forceinline__ const rcp_t* gamma_table(rcp_t* s_tab, const RenderAr
     if constexpr (DIST == kGamma || DIST == kGammaRev || DIST == -1) {
         const int lane = threadIdx.x & 63;
         if (lane < kGammaSteps - 1) s_tab[lane] = (rcp_t)(1. / (double)(a.p.dist_shape + (float)(lane + 1)));
+        __builtin_amdgcn_wave_barrier();
+        return s_tab;
+    } else {
+        return nullptr;
+    }
+}
+
+// the normal CDF's tables (gendr_math.h: norm_q_tab) in LDS, for the kernels specialised for the gaussian distribution; every wave
+// of a workgroup stores the same 192 doubles (three per lane) and reads them after its own stores
+#ifndef GENDR_NORMTAB_LDS
+#define GENDR_NORMTAB_LDS 1     // 0: the tables stay in global memory (read through the vector L1) -- A/B builds
+#endif
+template <int DIST>
+__device__ __forceinline__ const double* norm_table(double* s_tab)
+{
+    if constexpr (DIST == kGaussian) {
+#if !GENDR_NORMTAB_LDS
+        return &kNormTab[0][0];
+#endif
+        const int lane = threadIdx.x & 63;
+        const double* src = &kNormTab[0][0];
+#pragma unroll
+        for (int k = 0; k < kNormRows * kNormRow / 64; k++) s_tab[lane + 64 * k] = src[lane + 64 * k];
         __builtin_amdgcn_wave_barrier();
         return s_tab;
     } else {
@@ -891,7 +914,8 @@ __device__ __forceinline__ bool soft_fragment(Pair& q, const float* r, float xp,
         const bool squared = SQ >= 0 ? (SQ != 0) : (a.p.dist_squared != 0);
         if (!squared) dis = sqrt_rn(dis);                                           // :770-772 (== sqrtf, see sqrt_rn)
         q.dis = dis;
-        if constexpr (DIST >= 0)       q.frag = Dist<(DIST >= 0 ? DIST : 0)>::cdf(q.sign, dis, dp);
+        if constexpr (DIST == kGaussian) q.frag = norm_cdf_tab(div_by(q.sign * dis, dp.rscale), dp.norm_tab);   // Dist<kGaussian>::cdf with the LDS tables
+        else if constexpr (DIST >= 0)  q.frag = Dist<(DIST >= 0 ? DIST : 0)>::cdf(q.sign, dis, dp);
         else if constexpr (DIST == -2) q.frag = cdf_light_rt(dist, q.sign, dis, dp);
         else                           q.frag = cdf_rt(dist, q.sign, dis, dp);
     }
@@ -1852,7 +1876,8 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
     __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ double s_ntab[(DIST == kGaussian && GENDR_NORMTAB_LDS) ? kNormRows * kNormRow : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a), norm_table<DIST>(s_ntab)};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
     constexpr bool kSil = RGB == kRgbNone;       // alpha-only: `rgba` is one plane [B,is,is], nothing else is written
@@ -2024,6 +2049,13 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             barycentrics(q, r, pxp, pyp);
             FwdRes res;
             res.flags = 0; res.frag = 0.f; res.z = 0.f; res.c0 = res.c1 = res.c2 = 0.f; res.fn = fn; res.pad1 = 0;
+#if GENDR_ABLATE == 6       // phase table (tools/fwd_phases.sh): the gathers and the barycentrics only
+            res.frag = q.w0 + q.w1 + q.w2 + r[kRecEdge] + r[kRecXY + 5];
+            if (false)
+#elif GENDR_ABLATE == 7     // ... and the distance + CDF stage, nothing behind it
+            if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) { res.flags = kFlagContrib; res.frag = q.frag; hint = q.hint; }
+            if (false)
+#endif
             if (kSil) {
                 // alpha needs the fragment only: the reference folds it before it looks at the depth (:795-810)
                 if (soft_fragment<DIST, SQ>(q, r, pxp, pyp, a, dp)) { res.flags = kFlagContrib; res.frag = q.frag; hint = q.hint; }
@@ -2064,7 +2096,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             if (__ballot(hint_none(hint)) && lane == 0) atomicOr(a.control + (blockIdx.x & 7) * kCtlStride + kCtlHintFlag, 2);
         }
         __builtin_amdgcn_wave_barrier();
-#if GENDR_ABLATE == 2
+#if GENDR_ABLATE == 2 || GENDR_ABLATE == 6 || GENDR_ABLATE == 7
         alpha += s_res[wave][lane].frag; return;
 #endif
         // ---- phase C: every pixel folds its own pairs; their list positions ascend with the face index
@@ -2442,7 +2474,8 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     const int wave = threadIdx.x >> 6;
     const long P = (long)a.is * a.is;
     __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ double s_ntab[(DIST == kGaussian && GENDR_NORMTAB_LDS) ? kNormRows * kNormRow : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a), norm_table<DIST>(s_ntab)};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const int dist = DIST >= 0 ? DIST : a.p.dist_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
@@ -2839,7 +2872,8 @@ __device__ __forceinline__ void render_backward_faces_body(const RenderArgs& a, 
     constexpr int NG = GradSlots<TEXM>::n;
     const int lane = threadIdx.x & 63;
     __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ double s_ntab[(DIST == kGaussian && GENDR_NORMTAB_LDS) ? kNormRows * kNormRow : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a), norm_table<DIST>(s_ntab)};
     // Workgroups are dispatched round-robin over the 8 XCDs: XCD x takes the images x, x + 8, ... one after the other, so
     // that the planes of the image its waves are gathering from stay in that XCD's L2.
     const int xcd = blockIdx.x & 7;
@@ -2905,7 +2939,8 @@ __device__ __forceinline__ void render_backward_bands_body(const RenderArgs& a, 
     constexpr int NG = GradSlots<TEXM>::n;
     const int lane = threadIdx.x & 63;
     __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    __shared__ double s_ntab[(DIST == kGaussian && GENDR_NORMTAB_LDS) ? kNormRows * kNormRow : 1];
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a), norm_table<DIST>(s_ntab)};
     const int n = min(__builtin_amdgcn_readfirstlane(*a.det_count), kDetBigCap);
     const int nbands = (a.is + kDetBandRows - 1) / kDetBandRows;
     const long items = (long)n * nbands;
@@ -2963,13 +2998,16 @@ __global__ __launch_bounds__(256) void selftest_kernel(int what, unsigned long l
     // library's double normcdf rounded to float -- what the reference's kernel compiled for this platform computes -- on every
     // float u of [0, 6] (the polynomial's whole range and what lies beyond it)
     const bool ncdf = what >= 3;
+    __shared__ double s_ntab[kNormRows * kNormRow];          // what 3 / 4: the table form (norm_cdf_tab), 5 / 6: the polynomial form (norm_cdf)
+    for (int k = threadIdx.x; k < kNormRows * kNormRow; k += 256) s_ntab[k] = (&kNormTab[0][0])[k];
+    __syncthreads();
     const unsigned lo = ncdf ? 0u : __float_as_uint(0x1p-96f), hi = ncdf ? __float_as_uint(6.f) : __float_as_uint(0x1p+96f);
     unsigned long long bad = 0, n = 0;
     for (unsigned long long u = (unsigned long long)lo + blockIdx.x * 256ull + threadIdx.x; u <= hi; u += (unsigned long long)gridDim.x * 256ull) {
         float x = __uint_as_float((unsigned)u);
-        if (what == 2 || what == 4) x = -x;
+        if (what == 2 || what == 4 || what == 6) x = -x;
         float got, want;
-        if (ncdf)           { got = norm_cdf(x); want = (float)normcdf((double)x); }
+        if (ncdf)           { got = what <= 4 ? norm_cdf_tab(x, s_ntab) : norm_cdf(x); want = (float)normcdf((double)x); }
         else if (what == 0) { got = sqrt_rn(x); want = sqrtf(x); }
         else                { got = rcp_rn(x); want = 1.f / x; }
         n++;

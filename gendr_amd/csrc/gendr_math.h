@@ -70,12 +70,13 @@ struct DistParams {
     float  gamma_k0;       // (float)(1. / tgamma(shape + 1.)), first Kummer term
     double gamma_pdf_c;    // pow(1. / scale, shape) / tgamma(shape)
     const rcp_t* gamma_r;  // gamma_r[i - 1] = RN_double(1 / (double)(shape + i)), i = 1..31, or NULL: divide
+    const double* norm_tab; // kNormTab in LDS (the kernels specialised for the gaussian distribution: norm_cdf_tab), or NULL
 };
 
 GENDR_HD DistParams make_dist_params(float scale, float shape, float shift)
 {
     DistParams d = {scale, shape, shift, (rcp_t)(1. / (double)scale),
-                    (float)(1. / tgamma((double)shape + 1.)), pow(1. / (double)scale, (double)shape) / tgamma((double)shape), nullptr};
+                    (float)(1. / tgamma((double)shape + 1.)), pow(1. / (double)scale, (double)shape) / tgamma((double)shape), nullptr, nullptr};
     return d;
 }
 
@@ -309,6 +310,78 @@ GENDR_HD double norm_q(double x)             // Q(x) = Phi(-x) on [0, kNormQEnd]
 #pragma unroll
     for (int n = 29; n >= 0; n--) q = __builtin_fma(q, t, sconst(g[n]));
     return __builtin_ldexp(e, (int)k) * q;
+}
+// Round 6: the same Q(x) = e^(-x^2 / 2) g(x) from TABLES (tools/normcdf_table.py) -- what the kernels specialised for the gaussian distribution
+// (BASELINE config 3) evaluate: 18 double FMAs and 7 LDS reads per pair instead of 43 FMAs on scalar constants:
+//   * g on sixteen intervals of width 45/128, one polynomial of degree 10 in t = x - centre per interval (Chebyshev interpolants in
+//     60-digit arithmetic on intervals widened by 2^-12: the interval index comes from a rounded product);
+//   * e^y, y = -x^2 / 2 (exact): y = k ln2/16 + r, |r| <= ln2/32, e^r by a degree-7 Taylor polynomial, 2^(k/16) = 2^(k >> 4) T[k & 15].
+// Relative error of Q < 2^-51 against 60-digit values (20 000 random float arguments and the interval ends).  Row i of the table:
+// the eleven coefficients of interval i, constant term first, then T[i] = 2^(i/16).  The kernels copy it into LDS (norm_table()).
+constexpr int kNormRow = 12, kNormRows = 16;
+constexpr double kNormLn2_16Hi = 0.043321698784993146, kNormLn2_16Lo = 3.436201886692732e-15, kNorm16_Ln2 = 23.083120654223414;
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ const double kNormTab[kNormRows][kNormRow] = {
+    {0.43693140490055954, -0.32213793188376272, 0.1901527982808108, -0.096237545099447847, 0.043309010575230816, -0.017724927379106997, 0.0066988836797126543, -0.002363856377000447, 0.00078540348898180638, -0.00024913453600126088, 7.4695486193459816e-05, 1},
+    {0.34357789834435598, -0.21775862307140328, 0.11437212472952392, -0.052481732639003513, 0.021674052757761009, -0.0082104115210894588, 0.0028907240119249791, -0.0009551256301397116, 0.00029837461870584688, -8.9228541337659114e-05, 2.5316536962902442e-05, 1.0442737824274138},
+    {0.2791695527198545, -0.15357841570624881, 0.07209426164526761, -0.030071439518569408, 0.011416071376259407, -0.0040075566904269316, 0.0013156341585925701, -0.00040731349638098733, 0.00011970326110734182, -3.3766621964396342e-05, 9.0697235090130877e-06, 1.0905077326652577},
+    {0.23293616803301631, -0.11232160489205739, 0.047363971631746507, -0.0180139059742708, 0.0062996058161522497, -0.0020524876058942696, 0.00062901400608775899, -0.00018264143885079163, 5.0534065102882098e-05, -1.3455971607177274e-05, 3.4234066084388384e-06, 1.1387886347566916},
+    {0.19860566115621259, -0.084741918025393326, 0.032270649327551124, -0.011229580777076588, 0.0036262754034156242, -0.0010985399647981786, 0.00031472514712291001, -8.5804160884025307e-05, 2.2372183424093617e-05, -5.6280861495651065e-06, 1.3571606235107387e-06, 1.189207115002721},
+    {0.17236420204051464, -0.065659936612156383, 0.022702279490926479, -0.0072543169592247632, 0.0021688443894955171, -0.00061213060503208694, 0.00016420541528683062, -4.2088820489151983e-05, 1.0352692086229128e-05, -2.4629396042218772e-06, 5.6336963705045865e-07, 1.241857812073484},
+    {0.15180146102454875, -0.052052222982053711, 0.016426999175357559, -0.0048379877159034157, 0.0013428603272265737, -0.00035386841108253576, 8.903595373205243e-05, -2.1486628269413688e-05, 4.9918900104448469e-06, -1.1243078650330186e-06, 2.4416339756756753e-07, 1.2968395546510096},
+    {0.13534071474962242, -0.042086880182701666, 0.012184724321444768, -0.0033197297002514016, 0.00085788269396129655, -0.00021154686394275852, 5.0015519048947921e-05, -1.1381371451677492e-05, 2.5007249308868635e-06, -5.3384310783587177e-07, 1.1017619694594463e-07, 1.3542555469368927},
+    {0.12191833961535134, -0.034615992097746059, 0.0092380097397543135, -0.0023367402683716837, 0.00056379315241300164, -0.00013039355277858674, 2.9023424160954891e-05, -6.2376024033051704e-06, 1.2979496944962209e-06, -2.6294690147846116e-07, 5.1626586521538736e-08, 1.4142135623730951},
+    {0.11079686535493637, -0.028898062126156907, 0.0071409265878897583, -0.0016828276974605932, 0.00038013625504886711, -8.2646400540019955e-05, 1.7351698577003854e-05, -3.5277649065932105e-06, 6.9618221508824576e-07, -1.3401389873973592e-07, 2.5058836534341368e-08, 1.4768261459394993},
+    {0.10145225353860561, -0.024440797612439287, 0.0056156702385310774, -0.0012370257986617963, 0.00026232636848445032, -5.3734520577578675e-05, 1.0661737291786573e-05, -2.0539537988383873e-06, 3.849662868620553e-07, -7.0507052268039593e-08, 1.2570119502668261e-08, 1.5422108254079407},
+    {0.093503847674904314, -0.020909146247034379, 0.0044844114044822678, -0.00092627035885610822, 0.00018488232239368459, -3.5759381436715371e-05, 6.7180434865172664e-06, -1.2283602322428714e-06, 2.1897577814280515e-07, -3.8208566445642432e-08, 6.5022433735953418e-09, 1.6104903319492543},
+    {0.08666962815403631, -0.01806989105264031, 0.0036304636195565341, -0.00070523507483689516, 0.00013282151114729152, -2.4309358705199489e-05, 4.3322124590747322e-06, -7.5304364529789054e-07, 1.2786630477786665e-07, -2.1283726977290887e-08, 3.4613881253808612e-09, 1.681792830507429},
+    {0.080736905972542697, -0.015757355570810094, 0.0029755095906966182, -0.00054510269977988183, 9.7100268540722769e-05, -1.6851144437364709e-05, 2.8538595507033227e-06, -4.723505915438799e-07, 7.6504355292875934e-08, -1.2163888929344312e-08, 1.8926924247723499e-09, 1.7562521603732995},
+    {0.075542684520175846, -0.013851642515380009, 0.0024658862394416133, -0.00042713403836712731, 7.2125934792878444e-05, -1.1892163222149815e-05, 1.9172957750680814e-06, -3.0263508156577673e-07, 4.682045083025285e-08, -7.1199425609461804e-09, 1.061183720129842e-09, 1.8340080864093424},
+    {0.070960222219157085, -0.012264506980635265, 0.0020641204103867584, -0.00033888777936599807, 5.4361692229899524e-05, -8.5318053600651057e-06, 1.311669751600357e-06, -1.9774691139247489e-07, 2.926276228191101e-08, -4.2614744957419819e-09, 6.0908187955212908e-10, 1.9152065613971474},
+};
+#endif
+#ifndef GENDR_NORMCDF_TAB
+#define GENDR_NORMCDF_TAB 1
+#endif
+GENDR_HD double norm_q_tab(double x, const double* tab)      // Q(x) = Phi(-x) on [0, kNormQEnd]; tab: kNormTab in LDS
+{
+    const double y = -0.5 * (x * x);                                     // exact
+    const double k = __builtin_rint(y * sconst(kNorm16_Ln2));
+    double r = __builtin_fma(-k, sconst(kNormLn2_16Hi), y);              // (k * hi is exact: hi has 43 significant bits, |k| < 2^9)
+    r = __builtin_fma(-k, sconst(kNormLn2_16Lo), r);
+    double e = sconst(1. / 5040);
+    e = __builtin_fma(e, r, sconst(1. / 720));
+    e = __builtin_fma(e, r, sconst(1. / 120));
+    e = __builtin_fma(e, r, sconst(1. / 24));
+    e = __builtin_fma(e, r, sconst(1. / 6));
+    e = __builtin_fma(e, r, 0.5);
+    e = __builtin_fma(e, r, 1.);
+    e = __builtin_fma(e, r, 1.);
+    const int ki = (int)k;
+    int i = (int)(x * sconst(128. / 45.));
+    i = i > kNormRows - 1 ? kNormRows - 1 : i;
+    const double* row = tab + i * kNormRow;
+    const double t = x - (double)(2 * i + 1) * (45. / 256.);
+    double q = row[10];
+#pragma unroll
+    for (int n = 9; n >= 0; n--) q = __builtin_fma(q, t, row[n]);
+    return __builtin_ldexp(e * tab[(ki & 15) * kNormRow + 11], ki >> 4) * q;
+}
+GENDR_HD float norm_cdf(float u);
+// norm_cdf() for the kernels that hold the table in LDS (`tab`, see norm_table() in gendr_kernels.h)
+GENDR_HD float norm_cdf_tab(float u, const double* tab)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !GENDR_EXACT_CDF && GENDR_NORMCDF_POLY && GENDR_NORMCDF_TAB
+    if (u >= (float)kNormQEnd) return 1.f;
+    if (u > -(float)kNormQEnd) {
+        const double q = norm_q_tab((double)__builtin_fabsf(u), tab);
+        return (float)(u < 0.f ? q : 1. - q);
+    }
+    return 0.5f * erfcf(-u * 0.70710678118654752440f);       // (NaN ends up here and stays NaN)
+#else
+    (void)tab;
+    return norm_cdf(u);
+#endif
 }
 GENDR_HD float norm_cdf(float u)
 {

@@ -191,12 +191,13 @@ __device__ __forceinline__ void team_forward_body(const RenderArgs& a)
     __shared__ unsigned long long s_cnt[3][64];                          // chunk c -> buffer c % 3: per pixel, byte w = its pairs in B-wave w's batch
     __shared__ unsigned long long s_bmask[kTeamB][64];                   // private to a B-wave: per pixel, the pair lanes of its running batch
     __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    __shared__ double s_ntab[(DIST == kGaussian && GENDR_NORMTAB_LDS) ? kNormRows * kNormRow : 1];
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const bool folder = wave == 0;
     const int wb = wave - 1;                                             // B-wave 0 .. kTeamB - 1
     const long P = (long)a.is * a.is;
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a), norm_table<DIST>(s_ntab)};
     const int alpha_func = ALPHA >= 0 ? ALPHA : a.p.aggr_alpha_func;
     const bool rgb_soft = RGB >= 0 ? (RGB == 1) : (a.p.aggr_rgb_func == 1);
 
@@ -563,10 +564,11 @@ void render_backward_team_kernel(const RenderArgs a)
     __shared__ __attribute__((aligned(8))) FaceSeg s_seg[kTeamBwdWaves][64];
     __shared__ float s_val[kTeamBwdWaves][NG * 65];
     __shared__ rcp_t s_gamma[(DIST == kGamma || DIST == kGammaRev || DIST == -1) ? kGammaSteps : 1];
+    __shared__ double s_ntab[(DIST == kGaussian && GENDR_NORMTAB_LDS) ? kNormRows * kNormRow : 1];
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a)};
+    const DistParams dp = {a.p.dist_scale, a.p.dist_shape, a.p.dist_shift, GENDR_R_SCALE(a), a.gamma_k0, a.gamma_pdf_c, gamma_table<DIST>(s_gamma, a), norm_table<DIST>(s_ntab)};
 
     TileWalk tw;
     walk_init(tw, a, 1);

@@ -2,7 +2,9 @@
 sqrtf(x) and 1.f / x for EVERY float in [2^-96, 2^96]: exhaustive check on the GPU (1.6e9 bit patterns each).
 (2) The gaussian distribution's normal CDF (gendr_math.h: norm_cdf -- for u >= 0 a degree-30 polynomial in double, rounded
 once) against what the reference's kernel.cu:293 computes when compiled for this platform, the library's normcdf(double)
-rounded to float: every float of [0, 6] (1.09e9 bit patterns)."""
+rounded to float: every float of [0, 6] (1.09e9 bit patterns) -- for both device forms: the tables the kernels specialised for
+the gaussian distribution hold in LDS (round 6: norm_cdf_tab, what BASELINE config 3 runs) and the degree-30 polynomial of the
+runtime-dispatch kernels (norm_cdf)."""
 import ctypes
 
 import pytest
@@ -23,7 +25,7 @@ def test_short_forms_are_correctly_rounded_everywhere(native_lib, what, name):
     assert r[0] == 0, '%s: %d mismatches, e.g. bit patterns %s' % (name, r[0], [hex(v) for v in r[2:15] if v])
 
 
-@pytest.mark.parametrize("what,side", [(3, '+u'), (4, '-u')])
+@pytest.mark.parametrize("what,side", [(3, '+u, table form'), (4, '-u, table form'), (5, '+u, polynomial form'), (6, '-u, polynomial form')])
 def test_normal_cdf_is_the_librarys_double_one_rounded(native_lib, what, side):
     """Two double evaluations of Phi(u) with relative errors of 2^-50 and 2^-52 round to the same float unless Phi(u) lies that
     close to a rounding midpoint of the float grid: about 2^-25 of the inputs by measure.  Counted exhaustively on both sides
