@@ -704,7 +704,7 @@ def main():
             # Profiler figures of the same kernels: HBM traffic (separate rocprofv3 --pmc passes of FETCH_SIZE / WRITE_SIZE) and
             # the VALU occupation (SQ_ACTIVE_INST_VALU), read from profiles/pmc_<config>.json -- but only if that file was
             # collected on THESE kernel sources (it carries their hash): a stale file yields null, not a number.
-            traffic, valu_busy, source, lane_frac = None, None, None, None
+            traffic, valu_busy, source, lane_frac, valu_ratio = None, None, None, None, None
             pmc_path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % args.config)
             if os.path.exists(pmc_path):
                 try:
@@ -714,7 +714,11 @@ def main():
                         traffic = pmc.get('hbm_bytes_per_launch', {}).get(dom)
                         # (calibrated against a pure-VALU kernel of known occupation collected in the same profile run, when the file
                         # has it: tools/micro/valucal.hip)
-                        valu_busy = pmc.get('valu_busy_calibrated', pmc.get('valu_busy', {})).get(dom)
+                        # the figure relative to an all-FMA kernel EXCEEDS 1 for kernels with transcendental / f64 / cross-lane
+                        # instructions (the counter sums per-wave execution cycles, which overlap across pipes) -- it is an issue-rate
+                        # ratio, not a saturating fraction: reported under its own name, and `valu_busy` is that ratio clamped to 1
+                        valu_ratio = pmc.get('valu_issue_vs_fma_kernel', pmc.get('valu_busy_calibrated', {})).get(dom)
+                        valu_busy = min(1.0, valu_ratio) if valu_ratio is not None else pmc.get('valu_busy', {}).get(dom)
                         lane_frac = pmc.get('useful_lane_frac', {}).get(dom)
                         # traffic is quoted PER LAUNCH of this line's batch: the counter passes record the batch they ran at
                         # (C4 / C5 counters of one batch were set beside the algorithmic bytes of another); a pass at
@@ -725,8 +729,9 @@ def main():
                             traffic = traffic * B / tb
                             scaled = '; traffic measured at batch %d and scaled to this line\'s %d frames on rank 0' % (tb, B)
                         source = ('profiles/pmc_%s.json (kernel sources %s): rocprofv3 --pmc passes (profiles/run_all.sh): traffic = '
-                                  '2*FETCH_SIZE+WRITE_SIZE of bench.py at batch %s%s; valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * '
-                                  'kernel duration of the same counter pass * 2.4 GHz nominal), tools/kbench.py at batch %s; not re-measured in this run'
+                                  '2*FETCH_SIZE+WRITE_SIZE of bench.py at batch %s%s; valu_issue_vs_fma_kernel = (SQ_ACTIVE_INST_VALU / '
+                                  'SQ_BUSY_CYCLES) relative to tools/micro/valucal.hip in the same profile run -- a ratio that exceeds 1 for f64 / transcendental '
+                                  'mixes, valu_busy = that clamped to 1 -- tools/kbench.py at batch %s; not re-measured in this run'
                                   % (args.config, pmc['kernel_sha'], tb, scaled, pmc.get('sq_batch')))
                     else:
                         source = ('profiles/pmc_%s.json was collected on other kernel sources (%s, now %s): traffic and valu_busy withheld'
@@ -735,6 +740,7 @@ def main():
                     traffic = None
             out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'valu_busy': valu_busy,
+                               'valu_issue_vs_fma_kernel': valu_ratio,
                                # share of the issued vector lane-slots that did work: SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)
                                'useful_lane_frac': lane_frac, 'traffic_source': source,
                                'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,

@@ -1689,16 +1689,17 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
         // its class exceeds tc, 2 tc, 4 tc, with the smallest tc >= 2 (pieces of 64 pairs: one batch) whose work items fit `budget`
         int g8 = 0, g4 = 0, g2 = 0;
         if (team) {
-            // team calls (gendr_team.h): the backward teams take a heavy tile in 2, 4 or 8 PARTS -- ranges of its batches, there is no
+            // team calls (gendr_team.h): the backward teams take a heavy tile in 2 or 4 PARTS -- ranges of its batches, there is no
             // order to keep -- of at most kTeamPieceClasses x 512 pairs or so, whatever the number of teams: the parts are dealt out
             // heaviest tile first, so the teams' loads even out; the forward teams ignore the grades (a fold cannot be cut)
-            int n2 = 0, n4 = 0, n8 = 0;
+            // (2 or 4 parts: the classes end at kOrderClasses - 1 = 31 = tiles of 15 872 pairs and more, below the 4 x kTeamPieceClasses an
+            // 8-fold grade would start at -- ADVICE r5: the n8 count of round 5 was dead code)
+            int n2 = 0, n4 = 0;
             for (int c = kOrderClasses - 1; c > kTeamPieceClasses; c--) {
                 n2 += s_count[c];
                 if (c > 2 * kTeamPieceClasses) n4 += s_count[c];
-                if (c > 4 * kTeamPieceClasses) n8 += s_count[c];
             }
-            g8 = n8; g4 = n4 - n8; g2 = n2 - n4;
+            g8 = 0; g4 = n4; g2 = n2 - n4;
         } else if (live > 0 && live < budget) {
             int above[kOrderClasses + 1];                    // above[c] = tiles of a class > c
             above[kOrderClasses] = 0;

@@ -1,7 +1,7 @@
 """Stamps a traffic summary (tools/traffic_summary.py) with the kernel sources' hash and adds the VALU occupation of every
 kernel:   python tools/pmc_finalize.py <pmc_cfg.json> <dir of the SQ counter pass with SQ_ACTIVE_INST_VALU> <kernel_stats.csv> [sq batch] [dir of the calibration pass]
 valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles, MI355X_MICROARCH.md) * 4 / (1024 SIMDs * average kernel duration * 2.4 GHz);
-valu_busy_calibrated = that divided by what the same expression reads for tools/micro/valucal.hip -- a kernel whose vector ALUs are
+valu_issue_vs_fma_kernel (round 5: valu_busy_calibrated) = that divided by what the same expression reads for tools/micro/valucal.hip -- a kernel whose vector ALUs are
 occupied 100 % by construction -- under the same counters in the same gpurun call (the raw figure read 1.17 at
 saturation); useful_lane_frac = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU): the share of issued vector lane-slots that worked."""
 import collections, csv, glob, json, os, re, sys
@@ -113,9 +113,10 @@ if len(sys.argv) > 5:
                 vals = [x[1] for x in v if x[0] == g]
                 if quad.get(k) and vals:
                     vb[k] = (quad[k] / (sum(vals) / len(vals))) / r_cal
-            d['valu_busy_calibrated'] = vb
-        d['valu_busy_note'] += ('; valu_busy_calibrated = (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the same dispatch) / (the same ratio of '
-                                'tools/micro/valucal.hip, occupied 100 %% by construction, collected in the same gpurun call): a fraction, '
+            d['valu_issue_vs_fma_kernel'] = vb       # (round 5 called this valu_busy_calibrated; it exceeds 1 and is a ratio, not a fraction: ADVICE r5)
+        d['valu_busy_note'] += ('; valu_issue_vs_fma_kernel = (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the same dispatch) / (the same ratio of '
+                                'tools/micro/valucal.hip, occupied 100 %% by construction, collected in the same gpurun call): a RATIO that exceeds 1 for kernels with '
+                                'transcendental / f64 / cross-lane instructions (the counter sums per-wave execution cycles, which overlap across pipes), '
                                 'independent of the clock the pass ran at -- the raw valu_busy assumes 2.4 GHz, and the calibration kernel '
                                 'itself reads %.2f by that assumption because profiled dense-VALU passes clock at %.2f GHz' % (f_nom, 2.4 * f_nom))
 json.dump(d, open(path, 'w'), indent=1)
