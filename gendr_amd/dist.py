@@ -72,20 +72,67 @@ def _check_equal_blocks(n_local, group):
                          'pad the batch or shard it evenly' % (lo, hi))
 
 
+def _direct_all_gather(out, x, group):
+    """The all-gather as ONE round of point-to-point transfers: every rank sends its block to every peer and receives every
+    peer's block, all 2 (N - 1) transfers posted together (``batch_isend_irecv``: one RCCL group call).  On a node whose GPUs
+    are fully connected by point-to-point xGMI links (MI355X: 7 links per GPU) every transfer has its own link, so the
+    exchange takes one block time instead of the N - 1 serialised hops of a ring (0.9 ms for config 4's RGBA
+    views).  Same result as ``all_gather_into_tensor``, bit for bit (pure copies)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = x.shape[0]
+    out[rank * n:(rank + 1) * n].copy_(x)
+    ops = []
+    for step in range(1, world):                     # peers in rotating order: no two ranks start on the same receiver
+        to, frm = (rank + step) % world, (rank - step) % world
+        ops.append(dist.P2POp(dist.isend, x, dist.get_global_rank(group, to) if group is not None else to, group))
+        ops.append(dist.P2POp(dist.irecv, out[frm * n:(frm + 1) * n], dist.get_global_rank(group, frm) if group is not None else frm, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
+def _direct_reduce_scatter(out, grad, group):
+    """Backward of the direct all-gather: rank r receives block r of every peer's gradient in one round and sums the N blocks in
+    rank order (a fixed order: deterministic, unlike a ring's)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = out.shape[0]
+    recv = torch.empty((world,) + tuple(out.shape), dtype=grad.dtype, device=grad.device)
+    recv[rank].copy_(grad[rank * n:(rank + 1) * n])
+    ops = []
+    for step in range(1, world):
+        to, frm = (rank + step) % world, (rank - step) % world
+        ops.append(dist.P2POp(dist.isend, grad[to * n:(to + 1) * n], dist.get_global_rank(group, to) if group is not None else to, group))
+        ops.append(dist.P2POp(dist.irecv, recv[frm], dist.get_global_rank(group, frm) if group is not None else frm, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    torch.sum(recv, dim=0, out=out)
+
+
+def _algorithm(direct):
+    """'direct' | 'collective': the argument, else GENDR_ALLGATHER, else the library's collective."""
+    import os
+    if direct is None:
+        direct = os.environ.get('GENDR_ALLGATHER', 'collective') == 'direct'
+    return bool(direct)
+
+
 class _GatherViews(torch.autograd.Function):
     """All-gather of equally sized per-rank view blocks; backward = reduce-scatter of the gradient
     (each rank receives the sum over ranks of the gradient w.r.t. its own block)."""
 
     @staticmethod
-    def forward(ctx, x, group, checked):
+    def forward(ctx, x, group, checked, direct=False):
         ctx.group = group
+        ctx.direct = direct
         world = dist.get_world_size(group)
         if not checked:
             _check_equal_blocks(x.shape[0], group)
         x = x.contiguous()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         with _Timed(x):
-            dist.all_gather_into_tensor(out, x, group=group)
+            if direct:
+                _direct_all_gather(out, x, group)
+            else:
+                dist.all_gather_into_tensor(out, x, group=group)
         return out
 
     @staticmethod
@@ -93,27 +140,36 @@ class _GatherViews(torch.autograd.Function):
         group = ctx.group
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         n = grad.shape[0] // world
+        if ctx.direct:
+            grad = grad.contiguous()
+            out = torch.empty((n,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
+            with _Timed(grad):
+                _direct_reduce_scatter(out, grad, group)
+            return out, None, None, None
         if dist.get_backend(group) == 'gloo':          # gloo has no reduce_scatter: all-reduce a private copy and slice
             total = grad.clone(memory_format=torch.contiguous_format)   # never reduce in place into autograd's own buffer
             with _Timed(total):
                 dist.all_reduce(total, group=group)
-            return total[rank * n:(rank + 1) * n].clone(), None, None
+            return total[rank * n:(rank + 1) * n].clone(), None, None, None
         grad = grad.contiguous()
         out = torch.empty((n,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
         with _Timed(grad):
             dist.reduce_scatter_tensor(out, grad, group=group)
-        return out, None, None
+        return out, None, None, None
 
 
-def gather_views(images, group=None, assume_equal_blocks=False):
+def gather_views(images, group=None, assume_equal_blocks=False, direct=None):
     """[B_local, ...] on every rank -> [world * B_local, ...] on every rank, differentiable.
     A no-op without an initialised process group (single GPU).  Every rank must hand over the same number of
     views; that is verified with one small all-reduce per call unless ``assume_equal_blocks`` (callers that
     sharded with an even ``shard_range`` already know).  The check reads the result back on the host: a step that is to be
-    captured in a HIP graph has to pass ``assume_equal_blocks=True`` (the check raises inside a capture instead of breaking it)."""
+    captured in a HIP graph has to pass ``assume_equal_blocks=True`` (the check raises inside a capture instead of breaking it).
+    ``direct=True`` (or GENDR_ALLGATHER=direct): the one-round point-to-point form (``_direct_all_gather``) instead of the
+    library's collective, whose algorithm RCCL chooses -- on point-to-point xGMI a ring serialises N - 1 hops; not measured on a
+    multi-GPU node by any session, so the library's collective stays the default."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return images
-    return _GatherViews.apply(images, group, assume_equal_blocks)
+    return _GatherViews.apply(images, group, assume_equal_blocks, _algorithm(direct))
 
 
 def sum_over_ranks(t, group=None):
