@@ -277,9 +277,11 @@ int gendr_project_faces_backward(const float* vertices, const int* face_index, c
 
 /* Self-test of the short correctly-rounded forms the pair math uses for sqrtf(x) and 1.f / x (gendr_math.h: sqrt_rn,
  * rcp_rn): compares them with the compiler's IEEE expansions for EVERY float bit pattern in [2^-96, 2^96].
- *   what: 0 sqrt, 1 reciprocal of +x, 2 reciprocal of -x; 3 / 4: the normal CDF of the gaussian distribution at +u / -u
- *   (gendr_math.h: norm_cdf, e^(-u^2/2) times a degree-30 polynomial, in double) against the library's normcdf(double) rounded
- *   to float -- what the reference's kernel.cu:293 computes when compiled for this platform -- for every float u in [0, 6].
+ *   what: 0 sqrt, 1 reciprocal of +x, 2 reciprocal of -x; 3 / 4: the normal CDF of the gaussian distribution at +u / -u in the
+ *   TABLE form the kernels specialised for the gaussian evaluate (gendr_math.h: norm_cdf_tab -- e^(-u^2/2) g(u) in double from
+ *   tables in LDS; round 6), 5 / 6: the same in the polynomial form of the runtime-dispatch kernels (norm_cdf: a degree-30
+ *   polynomial) -- each against the library's normcdf(double) rounded to float, what the reference's kernel.cu:293 computes when
+ *   compiled for this platform, for every float u in [0, 6].
  *   report16 (device, 16 x u64): [0] mismatches, [1] values tested, [2..13] offending bit patterns, [14] largest difference
  *   in units of the last place. */
 int gendr_selftest(int what, unsigned long long* report16, void* stream);
