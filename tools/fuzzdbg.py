@@ -11,7 +11,7 @@ rs = np.random.RandomState(seed)
 names = [n for n, _ in scenes.OPTION_MATRIX]
 for case in range(n_cases):
     name, opts = scenes.OPTION_MATRIX[rs.randint(len(names))]
-    opts = dict(opts)
+    opts = scenes.independent_options(rs, opts)              # (the draw of tools/fuzz_parity.py since round 6)
     B = int(rs.choice([1, 2, 3, 5, 9])); nf = int(rs.choice([1, 2, 17, 63, 64, 65, 127, 130, 200])); isz = int(rs.choice([8, 13, 31, 64, 72, 100, 128, 136, 192, 200]))
     vertex = opts.get('texture_type') == 'vertex'
     T = 1 if vertex else int(rs.choice([1, 1, 4, 9]))
