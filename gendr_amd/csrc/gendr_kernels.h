@@ -112,6 +112,15 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 
 namespace gendr {
 
+// Set bits of a WAVE-UNIFORM 64-bit mask below this lane (plus `add`): v_mbcnt_lo / v_mbcnt_hi with the mask in scalar registers -- two vector
+// instructions where __popcll(m & lanes_below) costs two ANDs and two bit counts on a lane-mask register pair; and "is this lane's bit set"
+// as an exec mask straight from the scalar mask (no vector compare).  Round 6: 6 of the 13 vector instructions of the render kernels' append step.
+__device__ __forceinline__ int bits_below(unsigned long long m, int add = 0)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)add));
+}
+__device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // wave-uniform read-only data: loads through this pointer type with a uniform address become s_load_*
 #define GENDR_CONST_AS __attribute__((address_space(4)))
 typedef const GENDR_CONST_AS float* RecPtr;
@@ -1461,7 +1470,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                 const int cnt = __popcll(w);
                 if (nlist + cnt > kListCap) break;                       // the word stays in nz for the next round
                 nz &= nz - 1;
-                if (wave == 0 && ((w >> lane) & 1ull)) s_flist[nlist + __popcll(w & lt)] = (group0 + j) * 64 + lane;
+                if (wave == 0 && lane_in(w)) s_flist[bits_below(w, nlist)] = (group0 + j) * 64 + lane;
                 nlist += cnt;
             }
             if (WAVES > 1) { if (threadIdx.x == 0) s_pairs = 0; __syncthreads(); } else __builtin_amdgcn_wave_barrier();
@@ -1602,7 +1611,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                 e.fn = fn; e.npix = (__popc(v) + __popc(hi)) | (tag << 8); e.lo = v; e.hi = hi;
                 if (WAVES > 1) { my_ent = e; my_owns = owns; my_keep = keep; }
                 else {
-                    if (owns) out[nout + __popcll(keep & lt)] = e;
+                    if (owns) out[bits_below(keep, nout)] = e;
                     nout += __popcll(keep);
                 }
             }
@@ -1612,7 +1621,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                 int before = 0, all = 0;
 #pragma unroll
                 for (int k = 0; k < WAVES; k++) { const int c = s_cnt[k]; all += c; if (k < wave) before += c; }
-                if (my_owns) out[nout + before + __popcll(my_keep & lt)] = my_ent;
+                if (my_owns) out[bits_below(my_keep, nout + before)] = my_ent;
                 nout += all;
                 __syncthreads();                       // s_flist and s_cnt are rewritten by the next round
             } else __builtin_amdgcn_wave_barrier();
@@ -1825,7 +1834,7 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
                                          & pixels;              // this wave's rows of the tile, see sub_tile_mask
             j++;
             if (DENSE && m == ~0ull) { dense_fn = fn; dense_tag = (__builtin_amdgcn_readlane(e.y, j - 1) >> 8) & 3; break; }
-            if ((m >> lane) & 1ull) s_code[npairs + __popcll(m & lt)] = (fn << 6) | lane;
+            if (lane_in(m)) s_code[bits_below(m, npairs)] = (fn << 6) | lane;
             npairs += __popcll(m);
         }
         // ---- drain: the full batches; at the end of the tile, or ahead of a dense entry, the partial one as well
@@ -1966,7 +1975,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     PairHints* hint_slot = (hints_q && split_log2 == 0 && ti.y >= 0 && !pixel_mode) ? a.hints + ti.y : nullptr;   // next batch's slot (a tile without a slice of the entry pool has none)
     TileCtx t;
     tile_setup(t, a, ti.x);
-    t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels this wave renders
+    t.valid = t.valid && lane_in(my_rows);        // the pixels this wave renders
 
     s_xy[wave][lane] = make_float2(t.xp, t.yp);
 
@@ -2110,7 +2119,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     auto run_dense = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) {
         if constexpr (dense_path<DIST>()) {
             const long face_lin = (long)t.b * a.nf + fn;
-            const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
+            const bool mine = lane_in(mask) && t.valid;
             // the record arrives by scalar loads, stage by stage: a stage's floats are requested when the previous stage has been
             // consumed, so that only one stage occupies scalar registers at a time (the kernel has few to spare: the whole record
             // at once was spilled lane by lane)
@@ -2526,7 +2535,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     }
     TileCtx t;
     tile_setup(t, a, ti.x);
-    t.valid = t.valid && ((my_rows >> lane) & 1ull);        // the pixels whose pairs this wave differentiates
+    t.valid = t.valid && lane_in(my_rows);        // the pixels whose pairs this wave differentiates
     s_pix[wave][lane] = load_pixel_inputs<RGB>(a, t.b, t.pix, t.valid, t.xp, t.yp);
     GENDR_T(1);                                   // 1: tile record + the pixel's inputs parked in LDS
 #if GENDR_TRACE
@@ -2566,11 +2575,11 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
         const int fn_left = __builtin_amdgcn_update_dpp(-2, fn_l, 0x138, 0xF, 0xF, false);     // wave_shr:1, lane 0 keeps -2
         const unsigned long long heads = __ballot(lane < np && fn_l != fn_left);
         const int nfaces = __popcll(heads);
-        if ((heads >> lane) & 1ull) {
+        if (lane_in(heads)) {
             const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
             FaceSeg sg;
             sg.fn = fn_l; sg.span = lane | ((above ? __builtin_ctzll(above) + 1 : np - lane) << 8);
-            s_seg[wave][__popcll(heads & lt)] = sg;
+            s_seg[wave][bits_below(heads)] = sg;
         }
         if (lane < np) {
             const PixIn px = s_pix[wave][code & 63];
@@ -2637,7 +2646,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     auto run_dense = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) {
         if constexpr (dense_path<DIST>()) {
             const long face_lin = (long)t.b * a.nf + fn;
-            const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
+            const bool mine = lane_in(mask) && t.valid;
             const PixIn px = s_pix[wave][lane];
             float gv[9];
             float gt[NT];

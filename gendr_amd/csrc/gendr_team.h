@@ -102,7 +102,7 @@ __device__ __forceinline__ void team_build(const int4* __restrict__ ents, int cn
                 const int fn = __builtin_amdgcn_readlane(e.x, j);
                 const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, j) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, j)) & pixels;
                 const int base = built + __builtin_amdgcn_readlane(pos, j);
-                if ((m >> lane) & 1ull) s_ring[(base + __popcll(m & lt)) & (kTeamRing - 1)] = (fn << 6) | lane;
+                if (lane_in(m)) s_ring[bits_below(m, base) & (kTeamRing - 1)] = (fn << 6) | lane;
             }
         }
         built += total;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void team_forward_body(const RenderArgs& a)
         const float* recs_g = a.records + (long)t.b * a.nf * REC;
         const bool solo = ti.y < 0;                                      // one wave, lane = pixel: the tile has no slice of the entry pool
         const bool dense_tile = !solo && tile_in_pixel_mode(ti, 0);      // nearly full entries: lane = pixel, an entry per B-wave
-        t.valid = t.valid && ((my_rows >> lane) & 1ull);                 // the pixels this team renders
+        t.valid = t.valid && lane_in(my_rows);                 // the pixels this team renders
 
         FwdPix px;
         float bg[3];
@@ -314,7 +314,7 @@ __device__ __forceinline__ void team_forward_body(const RenderArgs& a)
         // lane = pixel, the face's record in scalar registers (run_dense of render_forward_body): the result of (face, this lane's pixel)
         auto dense_eval = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) -> TeamRes {
             const long face_lin = (long)t.b * a.nf + fn;
-            const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
+            const bool mine = lane_in(mask) && t.valid;
             float r[REC];
             RecPtr rs = uniform_rec_ptr(recs_g + (long)fn * REC);
             load_record<4 * kGatherW0, 4 * kGatherW1>(r, rs);
@@ -596,7 +596,7 @@ void render_backward_team_kernel(const RenderArgs a)
             const PixIn px = s_pix[lane];
             auto dense = [&](int fn, unsigned long long mask, int tag) __attribute__((always_inline)) {
                 const long face_lin = (long)t.b * a.nf + fn;
-                const bool mine = ((mask >> lane) & 1ull) != 0ull && t.valid;
+                const bool mine = lane_in(mask) && t.valid;
                 float gv[9];
                 float gt[NT];
                 int tex_own = -1;
@@ -692,11 +692,11 @@ void render_backward_team_kernel(const RenderArgs a)
                 const int fn_left = __builtin_amdgcn_update_dpp(-2, fn_l, 0x138, 0xF, 0xF, false);     // wave_shr:1, lane 0 keeps -2
                 const unsigned long long heads = __ballot(lane < np && fn_l != fn_left);
                 const int nfaces = __popcll(heads);
-                if ((heads >> lane) & 1ull) {
+                if (lane_in(heads)) {
                     const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
                     FaceSeg sg;
                     sg.fn = fn_l; sg.span = lane | ((above ? __builtin_ctzll(above) + 1 : np - lane) << 8);
-                    s_seg[wave][__popcll(heads & lt)] = sg;
+                    s_seg[wave][bits_below(heads)] = sg;
                 }
                 if (lane < np) {
                     const PixIn px = s_pix[code & 63];
