@@ -907,14 +907,20 @@ static int face_setup_impl(const float* faces, const float* textures, void* work
         // one 8-wave workgroup per listed tile, at most twice what the chip holds of them per queue
         const int per_queue = (int)((a.total_tiles + 7) / 8);
         const int tblocks = 8 * std::max(1, std::min(per_queue, 256));
-        if (texm == kTexSurface1)    hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurface1), 8>), dim3(tblocks), dim3(kThreads * 8), 0, s, a);
-        else if (texm == kTexVertex) hipLaunchKernelGGL((cover_kernel<record_floats(kTexVertex), 8>), dim3(tblocks), dim3(kThreads * 8), 0, s, a);
-        else                         hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurfaceN), 8>), dim3(tblocks), dim3(kThreads * 8), 0, s, a);
+#define GENDR_COVER_LAUNCH(W, GRID) do { \
+        if (a.want_tags) { \
+            if (texm == kTexSurface1)    hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurface1), W, true>), dim3(GRID), dim3(kThreads * W), 0, s, a); \
+            else if (texm == kTexVertex) hipLaunchKernelGGL((cover_kernel<record_floats(kTexVertex), W, true>), dim3(GRID), dim3(kThreads * W), 0, s, a); \
+            else                         hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurfaceN), W, true>), dim3(GRID), dim3(kThreads * W), 0, s, a); \
+        } else { \
+            if (texm == kTexSurface1)    hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurface1), W, false>), dim3(GRID), dim3(kThreads * W), 0, s, a); \
+            else if (texm == kTexVertex) hipLaunchKernelGGL((cover_kernel<record_floats(kTexVertex), W, false>), dim3(GRID), dim3(kThreads * W), 0, s, a); \
+            else                         hipLaunchKernelGGL((cover_kernel<record_floats(kTexSurfaceN), W, false>), dim3(GRID), dim3(kThreads * W), 0, s, a); \
+        } } while (0)
+        GENDR_COVER_LAUNCH(8, tblocks);
     } else {
         const int cblocks = render_blocks(a.total_blocks) * GENDR_COVER_GRID_MUL;
-        if (texm == kTexSurface1)    hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurface1)>, dim3(cblocks), dim3(kThreads), 0, s, a);
-        else if (texm == kTexVertex) hipLaunchKernelGGL(cover_kernel<record_floats(kTexVertex)>, dim3(cblocks), dim3(kThreads), 0, s, a);
-        else                         hipLaunchKernelGGL(cover_kernel<record_floats(kTexSurfaceN)>, dim3(cblocks), dim3(kThreads), 0, s, a);
+        GENDR_COVER_LAUNCH(1, cblocks);
     }
     e = check_launch();
     if (e != GENDR_OK) return e;

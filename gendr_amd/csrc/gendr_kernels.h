@@ -1406,7 +1406,10 @@ __device__ __forceinline__ unsigned quad_or(unsigned v)
     return v;
 }
 
-template <int REC, int WAVES = 1>
+// TAGS: the region tags of the entries are worked out (RenderArgs::want_tags).  A template parameter since round 6: as a run-time flag the
+// compiler had if-converted the second row's tag arithmetic -- 45 vector instructions per step that ran for every call, also where nobody
+// reads the tags (BASELINE config 2).
+template <int REC, int WAVES = 1, bool TAGS = false>
 __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArgs a)
 {
     // WAVES == 8 (team calls, gendr_params::team: few tiles, each listing faces by the hundred -- opt_shape.py's 64^2 images with
@@ -1514,6 +1517,16 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                 int cb_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(fminf((r[kRecBox + 1] - xs[0]) * half_is, 9.f), -2.f) + kColSlack));
                 if (pixel_coord(t.x0 + cb_first, a.is, a.r_is) < r[kRecBox + 0]) cb_first++;       // (NaN ends exclude nothing, as in inside_box())
                 if (pixel_coord(t.x0 + cb_last, a.is, a.r_is) > r[kRecBox + 1]) cb_last--;
+                // what does not depend on the row, once for the lane's two rows (the rows sit in branches of their own: the compiler does
+                // not share it by itself -- round 6: 15 vector instructions per step)
+                float tk3[3], dk3[3], rdk3[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float ak = r[kRecInv + 3 * k], bk = r[kRecInv + 3 * k + 1], ck = r[kRecInv + 3 * k + 2];
+                    tk3[k] = r[kRecWCull + k] - kSlack * (fabsf(ak) + fabsf(bk) + fabsf(ck));
+                    dk3[k] = ak * pitch;
+                    rdk3[k] = __builtin_amdgcn_rcpf(dk3[k]);
+                }
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
                     const float yp_a = yp_r[rr];
@@ -1524,10 +1537,10 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                     for (int k = 0; k < 3; k++) {
                         const float ak = r[kRecInv + 3 * k], bk = r[kRecInv + 3 * k + 1], ck = r[kRecInv + 3 * k + 2];
                         const float w = ak * xs[0] + bk * yp_a + ck;
-                        const float tk = r[kRecWCull + k] - kSlack * (fabsf(ak) + fabsf(bk) + fabsf(ck));
-                        const float dk = ak * pitch;
+                        const float tk = tk3[k];
+                        const float dk = dk3[k];
                         const float u = tk - w;                                        // the row passes where c dk >= u
-                        const float q = u * __builtin_amdgcn_rcpf(dk);
+                        const float q = u * rdk3[k];
                         const bool up = dk > 1e-30f, down = dk < -1e-30f;
                         lo = fmaxf(lo, up ? q : -1.f);
                         hi = fminf(hi, down ? q : 9.f);
@@ -1541,7 +1554,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                     // model w_k(0) + c d_k and the value barycentrics() computes for the pixel differ by less than half of that,
                     // see kSlack above).  Bits 0..2: w_k <= 0 NOT proven for the row; bits 3..5: w_k > 0 NOT proven.  NaN proves
                     // nothing.
-                    if (m8[rr] && a.want_tags) {
+                    if (TAGS && m8[rr]) {
                         const float cf = (float)c_first, cl = (float)c_last;
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
@@ -1592,7 +1605,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                 // evaluated per pixel gets no tag
                 const unsigned up = quad_or(unproven);
                 int tag = 0;
-                if (!loose_l && a.want_tags) {
+                if (TAGS && !loose_l) {
                     const int bits = __float_as_int(r[kRecBits]);
                     const bool n0 = !(up & 1u), n1 = !(up & 2u), n2 = !(up & 4u);          // w_k <= 0 on every pixel
                     const bool p0 = !(up & 8u), p1 = !(up & 16u), p2 = !(up & 32u);       // w_k > 0 on every pixel
