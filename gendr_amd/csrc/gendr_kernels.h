@@ -106,6 +106,22 @@ __device__ unsigned long long g_span_trace[3][1 << 16][2];
 #ifndef GENDR_PAIR_HINTS
 #define GENDR_PAIR_HINTS 1   // 0: no pair hints from the forward to the backward kernel (A/B builds)
 #endif
+#ifndef GENDR_RELOAD_ARGS
+#define GENDR_RELOAD_ARGS 1
+#endif
+// The kernel's arguments re-read from the kernarg segment at the top of a tile iteration (scalar loads through a pointer the compiler cannot
+// see through) instead of living in scalar registers from the kernel's first instruction on: the tile kernels need more scalar values than
+// the 102 registers hold, and the allocator's answer -- v_writelane at the start, v_readlane per tile -- is VECTOR instructions in kernels
+// bound by their vector issue.  Round 6: static vector instructions of C2's forward / backward kernel 976 -> 852 / 887 -> 809 (150 / 80 of
+// them lane moves), forward phase 0.133 -> 0.130 ms, backward 0.095 -> 0.092 ms.  The struct is the kernel's only parameter: offset 0.
+#if GENDR_RELOAD_ARGS
+#define GENDR_RELOADED_ARGS(a) \
+    const GENDR_CONST_AS RenderArgs* ap_ = (const GENDR_CONST_AS RenderArgs*)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(ap_)); \
+    const RenderArgs& a = *(const RenderArgs*)ap_
+#else
+#define GENDR_RELOADED_ARGS(a) do {} while (0)
+#endif
 #ifndef GENDR_ABLATE
 #define GENDR_ABLATE 0   // diagnostic builds only (tools/): 1, 2, 6, 7 cut the forward batch body short after a stage, 5 drops the fill (tools/fwd_phases.sh)
 #endif
@@ -1431,6 +1447,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
     // sixteen faces per step: the four lanes of a quad share a face, lane q of the quad tests pixel rows q and q + 4 of the tile
     const int slot = lane >> 2, prow = lane & 3;
     for (; tw.next < tw.total; tw.next += tw.stride) {
+        GENDR_RELOADED_ARGS(a);
         // The queue was appended to as the binning workgroups finished: the super-tiles under the object, with the most
         // faces to examine here, came last.  The waves take the slots from the back so that those start first.
         const int slot_c = tw.total - 1 - tw.next;
@@ -1978,6 +1995,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const bool hints_q = a.hints != nullptr;
     if (hints_q && tw.rank == 0 && (threadIdx.x & 63) == 0) atomicOr(a.control + (blockIdx.x & 7) * kCtlStride + kCtlHintFlag, 1);
     for (; tw.next < tw.items; tw.next += tw.stride) {
+    GENDR_RELOADED_ARGS(a);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int split_log2, sub;
@@ -2523,6 +2541,7 @@ __device__ __forceinline__ void render_backward_body(const RenderArgs& a)
     // 64 pairs in both
     const bool hinted_q = a.hints != nullptr && tw.hint_flag == 1;
     for (; tw.next < tw.items; tw.next += tw.stride) {
+    GENDR_RELOADED_ARGS(a);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int split_log2, sub;

@@ -285,6 +285,7 @@ __device__ __forceinline__ void team_forward_body(const RenderArgs& a)
     // A fold cannot be cut, a tile can: a forward part is 1, 2 or 4 of the tile's pixel rows (sub_tile_mask), rendered by a team of
     // its own -- the part's B-chain shrinks with its pairs, its fold runs on fewer lanes but is bound by latency, not by lanes.
     for (int item = tw.rank; item < (kTeamFwdRows ? tw.items : tw.live); item += tw.stride) {
+        GENDR_RELOADED_ARGS(a);
         int part_log2 = 0, part = 0;
         const int slot_i = kTeamFwdRows ? walk_item(tw, item, part_log2, part) : item;
         const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + slot_i));   // (tile, first entry, entries, pairs)
@@ -578,6 +579,7 @@ void render_backward_team_kernel(const RenderArgs a)
 
     // work items: (tile, part) -- order_tiles_kernel graded the heavy tiles into 8, 4 or 2 parts (TileWalk; team calls: by weight alone)
     for (int item = tw.rank; item < tw.items; item += tw.stride) {
+        GENDR_RELOADED_ARGS(a);
         int part_log2, part;
         const int slot_i = walk_item(tw, item, part_log2, part);
         const i4v ti = *(const GENDR_CONST_AS i4v*)(a.tile_info + (tw.qbase + slot_i));
