@@ -393,6 +393,10 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.p = *p;
     a.thr = p->dist_eps * p->dist_scale;                         // float * float, kernel.cu:725
     a.softmax_sum0 = expf(p->aggr_rgb_eps / p->aggr_rgb_gamma);  // kernel.cu:729
+    for (int k = 0; k < 3; k++) {
+        const volatile float prod = p->background[k] * a.softmax_sum0;          // (float product, then float quotient: the device's two roundings)
+        a.bg_soft[k] = prod / a.softmax_sum0;
+    }
     a.r_scale = 1. / (double)p->dist_scale;
     a.r_gamma = 1. / (double)p->aggr_rgb_gamma;
     a.r_zrange = 1. / (double)(p->far_ - p->near_);              // float subtraction first, as kernel.cu:826

@@ -333,6 +333,9 @@ struct RenderArgs {
     gendr_params p;
     float thr;                  // dist_eps * dist_scale (kernel.cu:725)
     float softmax_sum0;         // exp(aggr_rgb_eps / aggr_rgb_gamma) (kernel.cu:729)
+    float bg_soft[3];           // (background[k] * softmax_sum0) / softmax_sum0 in float, two roundings (kernel.cu:731-737, :857 for a pixel no face touches):
+                                // what an unlisted tile's pixels hold under softmax RGB -- from the host: as an expression of uniform values the
+                                // device evaluated an IEEE division per lane and fill (round 6)
     // correctly rounded double reciprocals of the per-call divisors (see div_by)
     double r_scale;             // 1 / dist_scale
     double r_gamma;             // 1 / aggr_rgb_gamma
@@ -1947,8 +1950,8 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         } else {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const float bgk = a.p.background_from_buffer ? out[k * P] : a.p.background[k];
-                out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0;
+                if (a.p.background_from_buffer) { const float bgk = out[k * P]; out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0; }
+                else out[k * P] = a.bg_soft[k];
             }
             if (with_aux) { aux[0] = a.softmax_sum0; aux[P] = a.p.aggr_rgb_eps; }
         }
@@ -1982,7 +1985,7 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
         float* aux = a.aux + (long)b * 2 * P + at;
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            fill_plane(out + k * P, rgb_soft ? (a.p.background[k] * a.softmax_sum0) / a.softmax_sum0 : a.p.background[k]);
+            fill_plane(out + k * P, rgb_soft ? a.bg_soft[k] : a.p.background[k]);
         fill_plane(out + 3 * P, 0.f);
         if (!a.p.skip_unlisted_aux) {
             fill_plane(aux, rgb_soft ? a.softmax_sum0 : 10000000.f);

@@ -236,8 +236,8 @@ __device__ __forceinline__ void team_forward_body(const RenderArgs& a)
             } else {
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const float bgk = a.p.background_from_buffer ? out[k * P] : a.p.background[k];
-                    out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0;
+                    if (a.p.background_from_buffer) { const float bgk = out[k * P]; out[k * P] = (bgk * a.softmax_sum0) / a.softmax_sum0; }
+                    else out[k * P] = a.bg_soft[k];
                 }
                 if (with_aux) { aux[0] = a.softmax_sum0; aux[P] = a.p.aggr_rgb_eps; }
             }
@@ -266,7 +266,7 @@ __device__ __forceinline__ void team_forward_body(const RenderArgs& a)
             float* aux = a.aux + (long)b * 2 * P + at;
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                fill_plane(out + k * P, rgb_soft ? (a.p.background[k] * a.softmax_sum0) / a.softmax_sum0 : a.p.background[k]);
+                fill_plane(out + k * P, rgb_soft ? a.bg_soft[k] : a.p.background[k]);
             fill_plane(out + 3 * P, 0.f);
             if (!a.p.skip_unlisted_aux) {
                 fill_plane(aux, rgb_soft ? a.softmax_sum0 : 10000000.f);
