@@ -355,6 +355,15 @@ int launch_deterministic_backward(RenderArgs& a, const void* workspace, int B, i
     return hipGetLastError() == hipSuccess ? GENDR_OK : GENDR_E_LAUNCH;
 }
 
+// (m, shift) with n / d == (n * m) >> shift for every 0 <= n < 2^30, d >= 1: m = ceil(2^(30 + l) / d), l = ceil(log2 d)  (m <= 2^31 + 1)
+static void div_magic(unsigned d, unsigned& m, int& shift)
+{
+    int l = 0;
+    while ((1ull << l) < d) l++;
+    shift = 30 + l;
+    m = (unsigned)(((1ull << shift) + d - 1) / d);
+}
+
 int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B, int nf, int T, const gendr_params* p)
 {
     const int texm = texture_mode(p, T);
@@ -387,6 +396,8 @@ int fill_args(RenderArgs& a, const void* workspace, const float* textures, int B
     a.tiles_x = w.tiles_x;
     a.tiles_per_image = w.tiles_x * w.tiles_x;
     a.total_tiles = a.tiles_per_image * B;
+    div_magic((unsigned)a.tiles_per_image, a.div_tpi_m, a.div_tpi_s);
+    div_magic((unsigned)a.tiles_x, a.div_tx_m, a.div_tx_s);
     a.total_blocks = (a.total_tiles + (kThreads / 64) - 1) / (kThreads / 64);
     a.chunks = w.chunks;
     a.rec_floats = record_floats(texm);

@@ -291,6 +291,9 @@ __device__ __forceinline__ long queue_begin(int x, long n_tiles) { return ((long
 // the x with queue_begin(x) <= g < queue_begin(x + 1)
 __device__ __forceinline__ int queue_of_tile(long g, long n_tiles) { return (int)min(7L, (8 * (g + 1) + n_tiles - 1) / n_tiles - 1); }
 
+// n / d for 0 <= n < 2^30 with the host's magic pair (see RenderArgs::div_tpi_m)
+__device__ __forceinline__ int fast_div(int n, unsigned m, int s) { return (int)(((unsigned long long)(unsigned)n * m) >> s); }
+
 struct RenderArgs {
     const float*  records;      // [B*nf][REC]
     const unsigned long long* masks;   // [B*tiles][chunks] : bit f of chunk c set = face 64c+f may touch the tile (binning -> coverage)
@@ -317,6 +320,11 @@ struct RenderArgs {
     PairHints*    hints;        // parallel to `entries`: slot (tile's first entry + k) = the hints of the tile's k-th batch of 64 pairs
     int B, nf, T, R, is;
     int tiles_x, tiles_per_image, total_tiles, total_blocks, chunks;
+    // n / tiles_per_image and n / tiles_x for tile indices n < 2^30 (gendr_validate) as a multiply and a shift -- on a wave-uniform n two scalar
+    // multiplies and a 64-bit shift -- where the compiler's expansion of an integer division converts to float and back on the vector pipes
+    // (five vector instructions per divisor and tile): m = ceil(2^(30 + l) / d), l = ceil(log2 d) (Granlund-Montgomery; div_magic() on the host)
+    unsigned div_tpi_m, div_tx_m;
+    int      div_tpi_s, div_tx_s;
     int*   det_count;           // deterministic backward: number of deferred (large-box) faces, their list, their band sums
     int*   det_list;
     float* det_partial;
@@ -756,9 +764,9 @@ __device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int 
 {
     const int lane = threadIdx.x & 63;
     t.tile = tile;
-    t.b = tile / a.tiles_per_image;
+    t.b = fast_div(tile, a.div_tpi_m, a.div_tpi_s);
     const int tl = tile - t.b * a.tiles_per_image;
-    const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
+    const int ty = fast_div(tl, a.div_tx_m, a.div_tx_s), tx = tl - ty * a.tiles_x;
     t.x0 = tx * kTile;
     t.y0 = ty * kTile;
     t.xi = t.x0 + (lane & 7);
@@ -1976,9 +1984,9 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
             for (int k = 0; k < n; k++) fill_tile(g0 + (k >> 3) * a.tiles_x + (k & 7));
             continue;
         }
-        const int b = g0 / a.tiles_per_image;
+        const int b = fast_div(g0, a.div_tpi_m, a.div_tpi_s);
         const int tl = g0 - b * a.tiles_per_image;
-        const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
+        const int ty = fast_div(tl, a.div_tx_m, a.div_tx_s), tx = tl - ty * a.tiles_x;
         const long at = (long)ty * 8 * a.is + tx * 8;
         if constexpr (kSil) { fill_plane(a.rgba + (long)b * P + at, 0.f); continue; }
         float* out = a.rgba + (long)b * 4 * P + at;

@@ -257,9 +257,9 @@ __device__ __forceinline__ void team_forward_body(const RenderArgs& a)
                 for (int k = 0; k < n; k++) fill_tile(g0 + (k >> 3) * a.tiles_x + (k & 7));
                 continue;
             }
-            const int b = g0 / a.tiles_per_image;
+            const int b = fast_div(g0, a.div_tpi_m, a.div_tpi_s);
             const int tl = g0 - b * a.tiles_per_image;
-            const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
+            const int ty = fast_div(tl, a.div_tx_m, a.div_tx_s), tx = tl - ty * a.tiles_x;
             const long at = (long)ty * 8 * a.is + tx * 8;
             if constexpr (kSil) { fill_plane(a.rgba + (long)b * P + at, 0.f); continue; }
             float* out = a.rgba + (long)b * 4 * P + at;
