@@ -146,6 +146,7 @@ typedef float f4v  __attribute__((ext_vector_type(4), aligned(4)));
 
 typedef float f2v  __attribute__((ext_vector_type(2), aligned(4)));
 typedef int   i4v  __attribute__((ext_vector_type(4)));
+typedef int   i16v __attribute__((ext_vector_type(16), aligned(16)));
 
 // Floats [BEGIN, END) of a face record -> dst[BEGIN..END) with the widest scalar loads that fit
 // (s_load_dwordx16 / x8 / x4 / x2): one wait per stage instead of one per field.
@@ -1814,6 +1815,9 @@ __device__ __forceinline__ bool tile_in_pixel_mode(const i4v& ti, int split_log2
     return split_log2 == 0 && ti.y >= 0 && ti.z > 0 && ti.w >= kPixelModeAvg * ti.z;
 }
 
+#ifndef GENDR_SCALAR_ENTRIES
+#define GENDR_SCALAR_ENTRIES 1
+#endif
 template <int REC, bool DENSE, typename Body, typename DenseBody>
 __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCtx& t, int off, int cnt, unsigned long long pixels, bool pixel_mode, int* s_code, Body body, DenseBody dense)
 {
@@ -1849,6 +1853,27 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
     for (;;) {
         // ---- fill: append entries until kFillCodes are listed, a dense entry turns up or the tile's entries are used up
         while (!done && npairs < kFillCodes) {
+#if GENDR_SCALAR_ENTRIES
+            if (off >= 0) {
+                // the tile's slice of the entry pool, four entries to a scalar load: face and mask arrive in scalar registers,
+                // no lane-indexed copy to read back (a load may run past the slice: into the next tile's entries, or the
+                // workspace block that follows the pool)
+                if (e0 >= cnt) { done = true; break; }
+                const i16v g = *(const GENDR_CONST_AS i16v*)(a.entries + off + e0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k > 0 && (e0 >= cnt || npairs >= kFillCodes)) break;
+                    const int fn = g[4 * k];
+                    const unsigned long long m = (((unsigned long long)(unsigned)g[4 * k + 3] << 32) | (unsigned)g[4 * k + 2]) & pixels;
+                    e0++;
+                    if (DENSE && m == ~0ull) { dense_fn = fn; dense_tag = (g[4 * k + 1] >> 8) & 3; break; }
+                    if (lane_in(m)) s_code[bits_below(m, npairs)] = (fn << 6) | lane;
+                    npairs += __popcll(m);
+                }
+                if (DENSE && dense_fn >= 0) break;
+                continue;
+            }
+#endif
             if (j == n) {
                 // next group of up to 64 entries into lane-indexed registers
                 j = 0; n = 0;
