@@ -255,9 +255,10 @@ constexpr int kThreads = 64;    // one wave-tile per workgroup (measured: 64 > 1
 //   [(16 + x) * kCtlStride]        : entries allocated so far in region x of the entry pool (bin_faces_kernel; 64-bit).
 constexpr int kCtlStride = 1024, kCtlInts = 24 * kCtlStride;
 
-// Per-face record of the binning kernel (floats): the cull box, then for each edge k the row (a, b, c) of the
-// barycentric matrix and wcull_k -- what the exact per-(face, tile) edge test needs, 64 bytes per face, coalesced.
-constexpr int kBinRec = 16;
+// Per-face record of the binning kernel (floats): the cull box (xlo, xhi, ylo, yhi), 16 bytes per face, coalesced.  (Until round 6 the
+// record also carried the rows of the barycentric matrix and wcull_k for a per-(face, tile) edge test that was measured in round 2 and
+// never shipped: 48 bytes per face that face_setup_kernel wrote and every super-tile's workgroup fetched past.)
+constexpr int kBinRec = 4;
 
 // One entry of a tile's coverage list: face index and the ballot of the tile's pixels that pass the exact box / edge
 // tests for it (bit p = pixel lane p).  Written by cover_kernel, read by both render kernels.
@@ -461,6 +462,9 @@ __device__ __forceinline__ float round_down(double v)
 // One thread per face.  Writes boxes[i][kBinRec] (the binning kernel's record) and records[i][REC].
 //   sthr   = sqrtf(dist_eps * dist_scale), the reference's border margin (:747)
 //   cull_r = distance beyond which an outside pixel contributes nothing (gendr_cull_radius), or +inf
+#ifndef GENDR_FS_ABLATE
+#define GENDR_FS_ABLATE 0      // 1, 2: measurement builds (tools/fs_ablate.sh), wrong results
+#endif
 template <int TEXM>
 __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const float* __restrict__ faces, const float* __restrict__ textures,
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     float xhi = xmax + sthr, xlo = xmin - sthr, yhi = ymax + sthr, ylo = ymin - sthr;
     float wcull[3] = {-INFINITY, -INFINITY, -INFINITY};
 
-    if (cull_r < INFINITY) {
+    if (cull_r < INFINITY && GENDR_FS_ABLATE != 2) {
         // Bound E on (true distance - computed distance) for pixel centres q = (x, y, 1), |x|,|y| <= 1.
         // The loop computes w = inv32 q (rounded) and the vector dis = sum_k (t_k - w_k) v_k with the closest
         // point c = sum_k t_k v_k on the triangle's boundary, i.e. dis = c - p_w with p_w = sum_k w_k v_k.
@@ -591,19 +595,8 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
         }
     }
 
-    // bin record: box, then (a, b, c, wcull) per edge.  The edge test is only handed over when the three coefficients are
-    // finite (a tile-corner evaluation of an infinite coefficient times a zero pixel coordinate would not bound the
-    // per-pixel value, which is NaN there and never rejected).
-    if (in_range) {
-        float4* b4 = reinterpret_cast<float4*>(boxes + i * kBinRec);
-        b4[0] = make_float4(xlo, xhi, ylo, yhi);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float a = g.inv[3 * k], b = g.inv[3 * k + 1], c = g.inv[3 * k + 2];
-            const bool finite = fabsf(a) < INFINITY && fabsf(b) < INFINITY && fabsf(c) < INFINITY;
-            b4[1 + k] = make_float4(a, b, c, finite ? wcull[k] : -INFINITY);
-        }
-    }
+    // bin record: the cull box (the binning kernel tests boxes only, see there)
+    if (in_range) reinterpret_cast<float4*>(boxes)[i] = make_float4(xlo, xhi, ylo, yhi);
 
     // the record leaves in 16-byte stores (REC is a multiple of 4 floats)
     float r[REC];
@@ -650,6 +643,10 @@ __global__ __launch_bounds__(kThreads) void face_setup_kernel(
     const int nrec = (int)min((long)kThreads, total_faces - first);
     float4* dst4 = reinterpret_cast<float4*>(records + first * REC);
     const float4* src4 = reinterpret_cast<const float4*>(s_out);
+#if GENDR_FS_ABLATE == 1        // measurement build: one 16-byte store per lane instead of the whole record
+    if ((threadIdx.x & 63) < nrec) dst4[threadIdx.x & 63] = src4[threadIdx.x & 63];
+    return;
+#endif
     for (int q = threadIdx.x & 63; q < nrec * (REC / 4); q += 64) dst4[q] = src4[q];
 }
 
@@ -761,21 +758,27 @@ __device__ __forceinline__ void walk_init(TileWalk& w, const RenderArgs& a, int 
     w.items = w.live + 7 * w.g8 + 3 * w.g4 + w.g2;
 }
 
-__device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int tile)
+// the lane = pixel part of a tile's context
+__device__ __forceinline__ void tile_lanes(TileCtx& t, const RenderArgs& a)
 {
     const int lane = threadIdx.x & 63;
-    t.tile = tile;
-    t.b = fast_div(tile, a.div_tpi_m, a.div_tpi_s);
-    const int tl = tile - t.b * a.tiles_per_image;
-    const int ty = fast_div(tl, a.div_tx_m, a.div_tx_s), tx = tl - ty * a.tiles_x;
-    t.x0 = tx * kTile;
-    t.y0 = ty * kTile;
     t.xi = t.x0 + (lane & 7);
     t.row = t.y0 + (lane >> 3);
     t.valid = t.xi < a.is && t.row < a.is;
     t.xp = pixel_coord(t.xi, a.is, a.r_is);
     t.yp = pixel_coord(a.is - 1 - t.row, a.is, a.r_is);   // yi = is - 1 - row, kernel.cu:716
     t.pix = (long)t.row * a.is + t.xi;
+}
+// lanes = false: the wave-uniform part only (the coverage kernel, whose lanes are (face, row) slots: tile_lanes() where it meets a loose face)
+__device__ __forceinline__ void tile_setup(TileCtx& t, const RenderArgs& a, int tile, bool lanes = true)
+{
+    t.tile = tile;
+    t.b = fast_div(tile, a.div_tpi_m, a.div_tpi_s);
+    const int tl = tile - t.b * a.tiles_per_image;
+    const int ty = fast_div(tl, a.div_tx_m, a.div_tx_s), tx = tl - ty * a.tiles_x;
+    t.x0 = tx * kTile;
+    t.y0 = ty * kTile;
+    if (lanes) tile_lanes(t, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1290,7 +1293,7 @@ __global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GEN
             const int fi = (c0 + ci) * 64 + lane;
             const bool have = fi < a.nf;
             float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
-            if (have) box = (reinterpret_cast<const float4*>(boxes) + ((long)b * a.nf + fi) * (kBinRec / 4))[0];
+            if (have) box = reinterpret_cast<const float4*>(boxes)[(long)b * a.nf + fi];
             if (have && a.loose_flag && a.loose_flag[(long)b * a.nf + fi]) box = loose_box_ndc(a.loose_box[(long)b * a.nf + fi], is, a.r_is);
             unsigned long long mine = 0ull;
             // Box test only (measured in round 2: an exact per-(face, tile) edge test removes a third of the listings but
@@ -1467,7 +1470,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
         const int tile = qi.x, off = qi.y;
         if (off < 0) continue;                      // no room in the pool: the render kernels test this tile themselves
         TileCtx t;
-        tile_setup(t, a, tile);
+        tile_setup(t, a, tile, false);
         const float* recs_g = a.records + (long)t.b * a.nf * REC;
         const unsigned long long* mrow = a.masks + (long)tile * a.chunks;
         const int row_a = t.y0 + prow;
@@ -1475,9 +1478,10 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
         const float yp_r[2] = {pixel_coord(a.is - 1 - row_a, a.is, a.r_is), pixel_coord(a.is - 5 - row_a, a.is, a.r_is)};
         CoverEnt* out = a.entries + off;
         int nout = 0;
-        float xs[8];                               // pixel centres of the tile's columns, and the nominal pixel pitch
-#pragma unroll
-        for (int c = 0; c < 8; c++) xs[c] = pixel_coord(t.x0 + c, a.is, a.r_is);
+        // pixel centres of the tile's columns: lane l holds column l & 7's (the exact box step below fetches its two columns with
+        // ds_bpermute -- a double-precision product each until round 6), xs0 = column 0's
+        const float xs_l = pixel_coord(t.x0 + (lane & 7), a.is, a.r_is);
+        const float xs0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xs_l)));
         const float pitch = (float)(2. * a.r_is);
         int my_pairs = 0;                          // pixels this lane's (face, row) slots found: summed into the tile's weight
 
@@ -1542,17 +1546,24 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                 // centre).  Rows: the y test below is the per-pixel expression.  Columns (the same for both rows): the widened ends,
                 // then one exact step at either end on the pixel centre pixel_coord() returns -- the render kernels' x.
                 const float half_is = 0.5f * (float)a.is;                          // 1 / pitch
-                int cb_first = max(0, (int)ceilf(fminf(fmaxf((r[kRecBox + 0] - xs[0]) * half_is, -1.f), 16.f) - kColSlack));
-                int cb_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(fminf((r[kRecBox + 1] - xs[0]) * half_is, 9.f), -2.f) + kColSlack));
-                if (pixel_coord(t.x0 + cb_first, a.is, a.r_is) < r[kRecBox + 0]) cb_first++;       // (NaN ends exclude nothing, as in inside_box())
-                if (pixel_coord(t.x0 + cb_last, a.is, a.r_is) > r[kRecBox + 1]) cb_last--;
+                int cb_first = max(0, (int)ceilf(fminf(fmaxf((r[kRecBox + 0] - xs0) * half_is, -1.f), 16.f) - kColSlack));
+                int cb_last = min(min(7, a.is - 1 - t.x0), (int)floorf(fmaxf(fminf((r[kRecBox + 1] - xs0) * half_is, 9.f), -2.f) + kColSlack));
+                // (a column outside 0..7 fetches some other column's centre: the interval is empty then, whatever the step does)
+                const float x_first = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(cb_first << 2, __builtin_bit_cast(int, xs_l)));
+                const float x_last = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(cb_last << 2, __builtin_bit_cast(int, xs_l)));
+                if (x_first < r[kRecBox + 0]) cb_first++;                                         // (NaN ends exclude nothing, as in inside_box())
+                if (x_last > r[kRecBox + 1]) cb_last--;
                 // what does not depend on the row, once for the lane's two rows (the rows sit in branches of their own: the compiler does
                 // not share it by itself -- round 6: 15 vector instructions per step)
                 float tk3[3], dk3[3], rdk3[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const float ak = r[kRecInv + 3 * k], bk = r[kRecInv + 3 * k + 1], ck = r[kRecInv + 3 * k + 2];
-                    tk3[k] = r[kRecWCull + k] - kSlack * (fabsf(ak) + fabsf(bk) + fabsf(ck));
+                    // threshold minus the row-independent part of w_k(0) = (ak x0 + ck) + bk y: the row passes where c dk >= tk3 - bk y.
+                    // That difference is rounded at the magnitude of the threshold (|wcull_k| <= Rf (|ak| + |bk|), a dozen times the
+                    // sum for a cull radius of several image widths), which the 2^-19 sum does not cover: the threshold (<= 0, or
+                    // -inf) is lowered by another 2^-21 of itself -- eight roundings of its magnitude.
+                    tk3[k] = (r[kRecWCull + k] * 1.000000476837158203125f - kSlack * (fabsf(ak) + fabsf(bk) + fabsf(ck))) - (ak * xs0 + ck);
                     dk3[k] = ak * pitch;
                     rdk3[k] = __builtin_amdgcn_rcpf(dk3[k]);
                 }
@@ -1565,10 +1576,8 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const float ak = r[kRecInv + 3 * k], bk = r[kRecInv + 3 * k + 1], ck = r[kRecInv + 3 * k + 2];
-                        const float w = ak * xs[0] + bk * yp_a + ck;
-                        const float tk = tk3[k];
                         const float dk = dk3[k];
-                        const float u = tk - w;                                        // the row passes where c dk >= u
+                        const float u = tk3[k] - bk * yp_a;                            // the row passes where c dk >= u
                         const float q = u * rdk3[k];
                         const bool up = dk > 1e-30f, down = dk < -1e-30f;
                         lo = fmaxf(lo, up ? q : -1.f);
@@ -1588,7 +1597,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
                             const float ak = r[kRecInv + 3 * k], bk = r[kRecInv + 3 * k + 1], ck = r[kRecInv + 3 * k + 2];
-                            const float w = ak * xs[0] + bk * yp_a + ck, dk = ak * pitch;
+                            const float w = ak * xs0 + bk * yp_a + ck, dk = ak * pitch;
                             const float mk = kSlack * (fabsf(ak) + fabsf(bk) + fabsf(ck));
                             const float wa = w + cf * dk, wb = w + cl * dk;
                             if (!(fmaxf(wa, wb) <= -mk) || !(wa == wa) || !(wb == wb)) unproven |= 1u << k;
@@ -1612,6 +1621,7 @@ __global__ __launch_bounds__(kThreads * WAVES) void cover_kernel(const RenderArg
                 // switched on from 1024^2 only; here it costs the affected tiles' waves ~1 us per flagged face, spread over the
                 // whole chip, and nothing anywhere else.)
                 unsigned long long flagged = __ballot(loose_l && prow == 0);
+                if (flagged) tile_lanes(t, a);
                 while (flagged) {
                     const int l = __builtin_ctzll(flagged);
                     flagged &= flagged - 1;
@@ -2835,7 +2845,7 @@ struct DetBox { int x0, W, yi0, yi1; bool empty; };
 // pixel centre of index i: (2 i + 1 - is) / is
 __device__ __forceinline__ DetBox det_box(const RenderArgs& a, const float* __restrict__ boxes, long face_lin)
 {
-    const float4 box = reinterpret_cast<const float4*>(boxes)[face_lin * (kBinRec / 4)];
+    const float4 box = reinterpret_cast<const float4*>(boxes)[face_lin];
     const double is_d = (double)a.is;
     auto first_index = [&](float v) { const double f = ceil(((double)v * is_d + is_d - 1.) * 0.5 - 1e-3); return f != f ? 0 : (int)fmin(fmax(f, 0.), is_d - 1.); };
     auto last_index = [&](float v) { const double f = floor(((double)v * is_d + is_d - 1.) * 0.5 + 1e-3); return f != f ? a.is - 1 : (int)fmin(fmax(f, 0.), is_d - 1.); };

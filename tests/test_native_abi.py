@@ -77,7 +77,7 @@ def test_validate_shapes(native_lib):
 
 def test_workspace_bytes(native_lib):
     p = _params(image_size=256)
-    # bin record 64 B + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile queue 4 B and queue record 16 B per tile, the entry pool (16 B per slot: 32 per tile + 64 per face, at most tiles * faces),
+    # bin record 16 B (the cull box; 64 B until round 6) + record 224 B per face, masks 8 B per (8x8 tile, 64-face chunk), tile queue 4 B and queue record 16 B per tile, the entry pool (16 B per slot: 32 per tile + 64 per face, at most tiles * faces),
     # the heavy-first copy of the queue records (16 B per tile, for 16 .. 2^19 tiles), control block (24 counters, 4 KiB apart); every part 256-byte aligned
     n = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(p))
     control = 24 * 1024 * 4
@@ -86,7 +86,7 @@ def test_workspace_bytes(native_lib):
     # + the pair hints (ABI 6; automatic: on for this 1.3-pixel cull radius): one 16-byte slot per pool entry
     # (the per-image lists of faces with a loose cull box exist from 1024^2 only -- loose_faces_kernel; below that the coverage kernel
     # resolves them without any buffer of its own: round 4)
-    assert n == 2 * 1280 * 64 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + pool + tiles * 16 + control
+    assert n == 2 * 1280 * 16 + 2 * 1280 * 224 + tiles * 20 * 8 + tiles * 4 + tiles * 16 + pool + pool + tiles * 16 + control
     # 1024^2: a flag (4 B) and a pixel box (16 B) per face, a list of 16 ints per image
     big1 = native_lib.gendr_workspace_bytes(2, 1280, 1, ctypes.byref(_params(image_size=1024)))
     q1 = _params(image_size=1016)
