@@ -23,7 +23,7 @@ def _entries(ws, B, nf, isz, rec_floats):
     tiles_x = (isz + 7) // 8
     tiles = B * tiles_x * tiles_x
     chunks = (nf + 63) // 64
-    off = a256(B * nf * 16 * 4) + a256(B * nf * rec_floats * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
+    off = a256(B * nf * 4 * 4) + a256(B * nf * rec_floats * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
     info = w[off:off + tiles * 16].view(np.int32).reshape(tiles, 4)
     ents = w[off + a256(tiles * 16):].view(np.int32)
     # only the first `queue length` records of each of the 8 queues were written by this call (the rest of the region is whatever

@@ -43,7 +43,7 @@ def _entries_per_tile(fv, tex, isz, opts):
     chunks = (nf + 63) // 64
     vertex = opts.get('texture_type') == 'vertex'
     rec = 60 if vertex else (56 if T == 1 else 48)
-    off = a256(B * nf * 16 * 4) + a256(B * nf * rec * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
+    off = a256(B * nf * 4 * 4) + a256(B * nf * rec * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
     info = w[off:off + tiles * 16].view(np.int32).reshape(tiles, 4)
     off += a256(tiles * 16)
     control = w[len(w) - 24 * 1024 * 4:].view(np.int32)            # kCtlInts = 24 x kCtlStride (1024); the last region of the layout

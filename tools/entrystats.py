@@ -31,7 +31,7 @@ tiles_x = (isz + 7) // 8
 tiles = Bn * tiles_x * tiles_x
 chunks = (nf + 63) // 64
 rec = {1: 56, 3: 60}.get(T, 48) if cfg['texture'] != 'vertex' else 60
-off = a256(Bn * nf * 16 * 4) + a256(Bn * nf * rec * 4)
+off = a256(Bn * nf * 4 * 4) + a256(Bn * nf * rec * 4)
 masks = w[off:off + tiles * chunks * 8].view(np.uint64); off += a256(tiles * chunks * 8)
 off += a256(tiles * 4)
 info = w[off:off + tiles * 16].view(np.int32).reshape(tiles, 4); off += a256(tiles * 16)

@@ -38,7 +38,7 @@ tiles_x = (isz + 7) // 8
 tiles = Bn * tiles_x * tiles_x
 chunks = (nf + 63) // 64
 rec = 60 if cfg['texture'] == 'vertex' else {1: 56}.get(T, 48)
-off = a256(Bn * nf * 16 * 4) + a256(Bn * nf * rec * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
+off = a256(Bn * nf * 4 * 4) + a256(Bn * nf * rec * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
 info = w[off:off + tiles * 16].view(np.int32).reshape(tiles, 4)
 control = w[len(w) - 24 * 1024 * 4:].view(np.int32)
 for x in range(8):

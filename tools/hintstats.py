@@ -30,7 +30,7 @@ tiles_x = (isz + 7) // 8
 tiles = Bn * tiles_x * tiles_x
 chunks = (nf + 63) // 64
 rec = 60 if cfg['texture'] == 'vertex' else {1: 56}.get(T, 48)
-info_off = a256(Bn * nf * 16 * 4) + a256(Bn * nf * rec * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
+info_off = a256(Bn * nf * 4 * 4) + a256(Bn * nf * rec * 4) + a256(tiles * chunks * 8) + a256(tiles * 4)
 ent_off = info_off + a256(tiles * 16)
 control_off = len(w) - 24 * 1024 * 4
 sorted_off = control_off - a256(tiles * 16)
