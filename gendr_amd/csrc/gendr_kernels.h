@@ -1286,14 +1286,23 @@ __global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GEN
     for (int c0 = 0; c0 < chunks; c0 += kBinGroup) {
         const int ng = min(kBinGroup, chunks - c0);
         constexpr int kPerWave = (kBinGroup + kBinWaves - 1) / kBinWaves;
+        // this wave's boxes of the group, all requested before the first one is used (round 6: the loads sat behind each other's
+        // candidate loops, one round trip to memory per chunk on the critical path of a workgroup that IS the kernel's duration)
+        float4 boxv[kPerWave];
+#pragma unroll
+        for (int u = 0; u < kPerWave; u++) {
+            const int ci = wave + u * kBinWaves;
+            const int fi = (c0 + ci) * 64 + lane;
+            boxv[u] = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);      // misses everything
+            if (ci < ng && fi < a.nf) boxv[u] = reinterpret_cast<const float4*>(boxes)[(long)b * a.nf + fi];
+        }
 #pragma unroll
         for (int u = 0; u < kPerWave; u++) {
             const int ci = wave + u * kBinWaves;
             if (ci >= ng) break;
             const int fi = (c0 + ci) * 64 + lane;
             const bool have = fi < a.nf;
-            float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);   // misses everything
-            if (have) box = reinterpret_cast<const float4*>(boxes)[(long)b * a.nf + fi];
+            float4 box = boxv[u];
             if (have && a.loose_flag && a.loose_flag[(long)b * a.nf + fi]) box = loose_box_ndc(a.loose_box[(long)b * a.nf + fi], is, a.r_is);
             unsigned long long mine = 0ull;
             // Box test only (measured in round 2: an exact per-(face, tile) edge test removes a third of the listings but
@@ -1392,15 +1401,14 @@ __global__ __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(GEN
         if (lane == 0) {
             if (listed) base_l = atomicAdd(a.control + x * kCtlStride, __popcll(listed));
             if (empty)  base_e = atomicAdd(a.control + (8 + x) * kCtlStride, __popcll(empty));
-            // Entries handed out so far in region x of the pool.  A 64-bit counter that is only advanced while the request
-            // fits: requests beyond the pool (nothing culled: every tile lists every face, 2.7e9 listings at 2048^2 x 5120
-            // faces x 64) cannot wrap it and land in another region's slice; a request that finds the region exhausted gets
-            // ent_cap8, i.e. no slice (ent_cap8 == 0: this option set has no pool at all, see entry_capacity).
+            // Entries handed out so far in region x of the pool (ent_cap8 == 0: this option set has no pool at all, see entry_capacity):
+            // a 64-bit counter, zeroed per call, that cannot wrap (nothing culled: 2.7e9 listings at 2048^2 x 5120 faces x 64).  A
+            // request that runs past the region leaves its tiles -- and every later request's -- without a slice, which the lanes
+            // find out by themselves below.  (Until round 6 the counter was read first and only advanced while the request fitted: a
+            // second dependent round trip to the memory-side atomic unit at the end of every workgroup.)
             if (need) {
-                unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.control + (16 + x) * kCtlStride);
                 base_n = a.ent_cap8;
-                if (a.ent_cap8 > 0 && (long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + need <= a.ent_cap8)
-                    base_n = (long)atomicAdd(ctr, (unsigned long long)need);
+                if (a.ent_cap8 > 0) base_n = (long)atomicAdd(reinterpret_cast<unsigned long long*>(a.control + (16 + x) * kCtlStride), (unsigned long long)need);
             }
         }
         base_l = __builtin_amdgcn_readfirstlane(base_l);
@@ -2010,7 +2018,14 @@ __device__ __forceinline__ void render_forward_body(const RenderArgs& a)
     const bool wide_ok = !a.p.background_from_buffer && ((reinterpret_cast<unsigned long long>(a.rgba) | (kSil ? 0ull : reinterpret_cast<unsigned long long>(a.aux))) & 15ull) == 0ull;
     // (... and the listed tiles whose coverage list came out empty -- behind the live ones in the heavy-first copy: same loop, so
     // that fill_tile is inlined once)
-    for (int r = tw.rank; r < tw.empties + (tw.total - tw.live); r += tw.stride) {
+#ifndef GENDR_FILL_DIV
+#define GENDR_FILL_DIV 2
+#endif
+    // which waves fill: the last 1 / GENDR_FILL_DIV of the queue's waves (dispatched last: their stores are spread over the launch
+    // instead of saturating the memory system while every wave of the first generation waits behind its share)
+    const int fill_stride = (GENDR_FILL_DIV > 1 && tw.stride >= 8 * GENDR_FILL_DIV) ? tw.stride / GENDR_FILL_DIV : tw.stride;
+    const int fill_first = tw.stride - fill_stride;
+    for (int r = tw.rank >= fill_first ? tw.rank - fill_first : 0x7fffffff; r < tw.empties + (tw.total - tw.live); r += fill_stride) {
         const int tile = __builtin_amdgcn_readfirstlane(r < tw.empties ? a.tile_list[tw.qend - 1 - r] : a.tile_info[tw.qbase + tw.live + (r - tw.empties)].x);
         // a negative entry is an empty super-tile (see bin_faces_kernel): tiles g0 + 8 rows of 8
         const int g0 = tile < 0 ? -tile - 1 : tile;
