@@ -1836,6 +1836,9 @@ __device__ __forceinline__ bool tile_in_pixel_mode(const i4v& ti, int split_log2
 #ifndef GENDR_SCALAR_ENTRIES
 #define GENDR_SCALAR_ENTRIES 1
 #endif
+#ifndef GENDR_SE_GROUP
+#define GENDR_SE_GROUP 8          // entries per round of scalar loads (4 or 8: two s_load_dwordx16 in flight; +0.7 % at C2 batch 64, +1 % at batch 1)
+#endif
 template <int REC, bool DENSE, typename Body, typename DenseBody>
 __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCtx& t, int off, int cnt, unsigned long long pixels, bool pixel_mode, int* s_code, Body body, DenseBody dense)
 {
@@ -1873,18 +1876,22 @@ __device__ __forceinline__ void for_each_batch(const RenderArgs& a, const TileCt
         while (!done && npairs < kFillCodes) {
 #if GENDR_SCALAR_ENTRIES
             if (off >= 0) {
-                // the tile's slice of the entry pool, four entries to a scalar load: face and mask arrive in scalar registers,
+                // the tile's slice of the entry pool, eight entries to a round of two scalar loads: face and mask arrive in scalar registers,
                 // no lane-indexed copy to read back (a load may run past the slice: into the next tile's entries, or the
                 // workspace block that follows the pool)
                 if (e0 >= cnt) { done = true; break; }
-                const i16v g = *(const GENDR_CONST_AS i16v*)(a.entries + off + e0);
+                const GENDR_CONST_AS i16v* gp = (const GENDR_CONST_AS i16v*)(a.entries + off + e0);
+                i16v gq[GENDR_SE_GROUP / 4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int q = 0; q < GENDR_SE_GROUP / 4; q++) gq[q] = gp[q];
+#pragma unroll
+                for (int k = 0; k < GENDR_SE_GROUP; k++) {
                     if (k > 0 && (e0 >= cnt || npairs >= kFillCodes)) break;
-                    const int fn = g[4 * k];
-                    const unsigned long long m = (((unsigned long long)(unsigned)g[4 * k + 3] << 32) | (unsigned)g[4 * k + 2]) & pixels;
+                    const i16v g = gq[k >> 2];
+                    const int fn = g[4 * (k & 3)];
+                    const unsigned long long m = (((unsigned long long)(unsigned)g[4 * (k & 3) + 3] << 32) | (unsigned)g[4 * (k & 3) + 2]) & pixels;
                     e0++;
-                    if (DENSE && m == ~0ull) { dense_fn = fn; dense_tag = (g[4 * k + 1] >> 8) & 3; break; }
+                    if (DENSE && m == ~0ull) { dense_fn = fn; dense_tag = (g[4 * (k & 3) + 1] >> 8) & 3; break; }
                     if (lane_in(m)) s_code[bits_below(m, npairs)] = (fn << 6) | lane;
                     npairs += __popcll(m);
                 }
