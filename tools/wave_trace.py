@@ -72,6 +72,14 @@ print('  batches per busy wave: mean %.2f max %d; (first batch -> end) / batches
       % (nb.mean(), int(nb.max()), us(np.median((b[has, 4] - b[has, 3]) / nb))))
 for i in np.argsort(end)[-5:]:
     print('  a last wave: start %.1f, end %.1f us, %d batches' % (start[i], end[i], int(tr[i, 5])))
+if os.environ.get('WAVE_TRACE_RANKS'):
+    # queue 0's busy waves by rank (w = blockIdx * 4 + wave; rank = (blockIdx >> 3) * 4 + wave, queue = blockIdx & 7): start, end, batches
+    w = np.arange(nw); blk = w >> 2; rank = (blk >> 3) * 4 + (w & 3)
+    sel = np.where(((blk & 7) == 0) & busy)[0]
+    sel = sel[np.argsort(rank[sel])]
+    step = max(1, len(sel) // 48)
+    print('  queue 0, busy waves by rank (every %d-th): rank start end batches' % step)
+    print('   ', ' | '.join('%d %.1f %.1f %d' % (rank[i], start[i], end[i], int(tr[i, 5])) for i in sel[::step]))
 edges = np.arange(0, end.max() + 5, 5.0)
 print('  waves alive per 5-us bin (all / with a tile):',
       ' '.join('%d/%d' % (int(((start < e + 5) & (end > e)).sum()), int(((start < e + 5) & (end > e) & busy).sum())) for e in edges[:-1]))
