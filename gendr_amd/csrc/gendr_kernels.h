@@ -1793,10 +1793,12 @@ __global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const Render
 // in a wavefront-private LDS buffer from the tile's coverage entries, and handed to body(first code, pairs) in batches of
 // 64 consecutive codes -- lane l of phase B takes code l of the batch.  A batch is just a window of the list: faces are
 // split wherever the window ends, every batch but the tile's last is full.
-//   * entries arrive 64 at a time by one coalesced 16-byte load per lane; v_readlane hands (face, mask) to the wave-uniform
-//     append step: the lanes (= pixels) whose bit is set store their code at list position base + (set bits below the lane)
-//     -- ten instructions per entry, no per-batch bookkeeping (round 2 built the batches entry by entry with their face
-//     tables and split decisions: ~45 instructions per entry, and per tile that was as much as a batch of pair math);
+//   * entries of the tile's slice of the pool arrive eight at a time by two scalar loads (face and mask in scalar registers:
+//     round 6; pixel mode and the fallback below keep up to 64 entries in lane-indexed registers read back with v_readlane);
+//     the wave-uniform append step: the lanes (= pixels) whose bit is set store their code at list position base + (set bits
+//     below the lane, v_mbcnt on the scalar mask) -- five vector instructions per entry, no per-batch bookkeeping (round 2
+//     built the batches entry by entry with their face tables and split decisions: ~45 instructions per entry, and per tile
+//     that was as much as a batch of pair math);
 //   * entries are appended until at least kFillCodes are listed; the full batches run -- from ONE call site, so that the
 //     caller's phase B is compiled once -- and the remainder (< 64 codes) moves to the front of the buffer;
 //   * `pixels` restricts the list to the pixel rows this wave renders (sub-tile split, see TileWalk);
