@@ -781,7 +781,7 @@ def main():
                     extra['caller_shapes'] = caller_shapes_extra(dev)
                 except Exception as e:
                     extra['caller_shapes'] = {'error': '%s: %s' % (type(e).__name__, e)}
-            sweep = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_%s_batch_sweep.json' % (r, args.config)) for r in (5, 4, 3))
+            sweep = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_%s_batch_sweep.json' % (r, args.config)) for r in (6, 5, 4, 3))
                           if os.path.exists(q)), '')
             if os.path.exists(sweep):
                 try:
