@@ -41,12 +41,15 @@ ent = w[off:off + cap * 16].view(np.uint32).reshape(cap, 4)
 control = w[control_off:].view(np.int32)
 nlisted = [int(control[x * 1024]) for x in range(8)]
 listings = 0                                              # mask rows of listed tiles only: the others are never written
+list_per_tile = []
 for x in range(8):
     qb = x * tiles // 8
     for s_ in range(nlisted[x]):
         row = masks[int(info[qb + s_][0]) * chunks:(int(info[qb + s_][0]) + 1) * chunks]
-        listings += int(sum(bin(int(m)).count('1') for m in row))
+        n_ = int(sum(bin(int(m)).count('1') for m in row))
+        listings += n_; list_per_tile.append(n_)
 n_entries = n_pairs = n_batches = fallback = 0
+rows_hist = np.zeros(9, np.int64)
 per_tile = []
 for x in range(8):
     qb = x * tiles // 8
@@ -57,6 +60,7 @@ for x in range(8):
             continue
         e = ent[first:first + cnt]
         pc = np.array([bin(int(lo)).count('1') + bin(int(hi)).count('1') for lo, hi in e[:, 2:4]], dtype=np.int64)
+        rows_hist += np.bincount([sum(1 for r in range(8) if ((int(lo) | (int(hi) << 32)) >> (8 * r)) & 255) for lo, hi in e[:, 2:4]], minlength=9)[:9]
         n_entries += cnt
         n_pairs += int(pc.sum())
         n_batches += int(np.ceil(pc.sum() / 64.0))
@@ -66,6 +70,9 @@ print('%s batch %d: %d tiles, %d listed (%.1f %%), %s listings (bin), %d entries
       '%.2f pairs per pixel, >= %d batches (%.1f per listed tile), %d tiles without a pool slice'
       % (args.config, Bn, tiles, sum(nlisted), 100.0 * sum(nlisted) / tiles, listings, n_entries, n_entries / max(1, sum(nlisted)),
          n_pairs, n_pairs / max(1, n_entries), n_pairs / float(Bn * P), n_batches, n_batches / max(1, sum(nlisted)), fallback))
+lp = np.array(list_per_tile)
+print('faces listed by the binning kernel per listed tile, percentiles [0, 10, 25, 50, 75, 90, 99, 100]:', [int(v) for v in np.percentile(lp, [0, 10, 25, 50, 75, 90, 99, 100])], ' mean %.1f;  sixteen-face steps per tile: mean %.2f' % (lp.mean(), np.ceil(lp / 16.0).mean()))
+print('pixel rows per entry (histogram 0..8):', rows_hist.tolist(), ' mean %.2f' % ((rows_hist * np.arange(9)).sum() / max(1, rows_hist.sum())))
 pt = np.array([t[0] for t in per_tile]); en = np.array([t[1] for t in per_tile])
 q = [0, 10, 25, 50, 75, 90, 99, 100]
 print('pairs per listed tile, percentiles', q, ':', [int(v) for v in np.percentile(pt, q)], ' mean %.0f' % pt.mean())
